@@ -1,0 +1,228 @@
+"""The CPU oracle (oracle/gp_oracle.py) against the golden vectors produced by the
+real reference (tests/golden/make_golden.py) and against the known answers saved
+in the reference's moments_gradients.ipynb.  CPU only."""
+import warnings
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, relerr
+from oracle import gp_oracle as orc
+from gaussian_processes_amd import synthetic as syn
+
+KEYS = orc.THETA_KEYS
+LOWER, UPPER = orc.default_limits()
+
+
+def thd(vec):
+    return {k: float(v) for k, v in zip(KEYS, vec)}
+
+
+def T(a):
+    return torch.from_numpy(np.asarray(a, dtype=np.float64))
+
+
+def test_linspace_matches_torch():
+    for n in (2, 3, 8, 12, 16, 17, 108):
+        assert torch.equal(orc.linspace_pm1(n), torch.linspace(-1, 1, n, dtype=torch.float64))
+
+
+def test_g1_localker():
+    g = load_golden("g1_localker.npz")
+    for i in range(int(g["n_cases"])):
+        th = thd(g[f"c{i}_theta"])
+        C, mask, dC = orc.spatial_metric(th, LOWER, UPPER, int(g[f"c{i}_n_px"]), grad=True)
+        assert np.array_equal(mask.numpy(), g[f"c{i}_mask"])
+        assert relerr(C, g[f"c{i}_C"]) < 1e-14
+        for k in orc.DC_KEYS:
+            assert relerr(dC[k], g[f"c{i}_dC_{k}"]) < 1e-14, k
+    # the last two cases have a partially-false mask
+    assert not g["c2_mask"].all() and not g["c3_mask"].all()
+
+
+def test_localker_limits_raise():
+    th = syn.theta_eval()
+    th["eps_0x"] = 1.5
+    with pytest.raises(ValueError):
+        orc.spatial_metric(th, LOWER, UPPER, 8)
+
+
+def test_g2_acosker():
+    g = load_golden("g2_acosker.npz")
+    th = thd(g["theta"])
+    C, mask, dC = orc.spatial_metric(th, LOWER, UPPER, int(g["n_px"]), grad=True)
+    X, X2, X1 = T(g["X"])[:, mask], T(g["X2"])[:, mask], T(g["X1row"])[:, mask]
+    K, dK = orc.arccos_gram(th, X, X, C, dC)
+    assert relerr(K, g["Ksq"]) < 1e-13
+    for k in KEYS:
+        assert relerr(dK[k], g[f"dKsq_{k}"]) < 1e-12, k
+    K, dK = orc.arccos_gram(th, X, X2, C, dC)
+    assert relerr(K, g["Krc"]) < 1e-13
+    for k in KEYS:
+        assert relerr(dK[k], g[f"dKrc_{k}"]) < 1e-12, k
+    assert relerr(orc.arccos_gram(th, X1, X, C), g["K1"]) < 1e-13
+    Kv, dKv = orc.arccos_gram_diag(th, X, C, dC)
+    assert relerr(Kv, g["Kv"]) < 1e-14
+    for k in KEYS:
+        assert relerr(dKv[k], g[f"dKv_{k}"]) < 1e-13, k
+    assert relerr(orc.arccos_gram_diag(th, X1, C), g["Kv1"]) < 1e-14
+    Xd = T(g["X"]).clone()
+    Xd[1] = Xd[0]
+    Xd[2] = -Xd[0]
+    assert relerr(orc.arccos_gram(th, Xd[:, mask], Xd[:, mask], C), g["Kdup"]) < 1e-13
+    # diag(K) = Kvec - 1e-7 (SURVEY a-note 2) up to the J expansion
+    assert np.allclose(np.diag(g["Ksq"]), g["Kv"] - 1e-7, rtol=0, atol=2e-9)
+
+
+def _closure_inputs(g):
+    N, d = int(g["N"]), int(g["d"])
+    if "X" in g.files:
+        X, r, B, m_b, V_b = T(g["X"]), T(g["r"]), T(g["B"]), T(g["m_b"]), T(g["V_b"])
+    else:  # inputs regenerated from the seed (fixture stores outputs only)
+        X = T(syn.stimuli(N, d, seed=int(g["seed"])))
+        r_np, m_np = syn.cell_inputs(N)
+        r, m = T(r_np), T(m_np)
+        th0 = thd(g["theta0"])
+        C0, mask0 = orc.spatial_metric(th0, LOWER, UPPER, int(g["n_px"]))
+        Kt0 = orc.arccos_gram(th0, X[:, mask0], X[:, mask0], C0)
+        V = 0.5 * Kt0
+        ev, evec, keep = orc.eigen_basis(Kt0, float(g["tol"]))
+        assert int(keep.sum()) == int(g["n_kept"])
+        B = evec[:, keep]
+        m_b, V_b = B.T @ m, B.T @ V @ B
+    return X, r, B, m_b, V_b
+
+
+@pytest.mark.parametrize("name", ["g3_closure_full_N64.npz", "g3_closure_full_N256.npz",
+                                  "g3_closure_full_N192_d16.npz", "g3_closure_trunc_N96_d16.npz",
+                                  "g3_closure_sparse_N96_nt40.npz", "g3_closure_full_N512.npz"])
+def test_g3_closure_reference_formulation(name):
+    g = load_golden(name)
+    X, r, B, m_b, V_b = _closure_inputs(g)
+    nt_ = int(g["ntilde"])
+    xtilde = X[:nt_]
+    loss, grad, parts = orc.mstep_closure_reference(
+        thd(g["theta"]), LOWER, UPPER, int(g["n_px"]), X, xtilde, r, B, m_b, V_b,
+        float(g["logA"]), float(g["lambda0"]), tol=float(g["tol"]), want_parts=True)
+    assert abs(loss - float(g["loss"])) <= 1e-11 * abs(float(g["loss"]))
+    assert abs(parts["KL"] - float(g["KL"])) <= 1e-11 * abs(float(g["KL"]))
+    assert abs(parts["loglik"] - float(g["loglik"])) <= 1e-11 * abs(float(g["loglik"]))
+    gv = np.array([grad[k] for k in KEYS])
+    assert relerr(gv, g["grad"]) < 1e-8
+    assert relerr(parts["lam_m"], g["lam_m"]) < 1e-11
+    assert relerr(parts["lam_var"], g["lam_var"]) < 1e-10
+
+
+@pytest.mark.parametrize("name", ["g3_closure_full_N64.npz", "g3_closure_full_N256.npz",
+                                  "g3_closure_full_N192_d16.npz", "g3_closure_full_N512.npz"])
+def test_g3_closure_cholesky_formulation(name):
+    """The original-basis Cholesky restatement (what the HIP path implements) equals the
+    reference on the full-rank family: 1e-10 rel on the loss, 1e-7 on the gradients."""
+    g = load_golden(name)
+    X, r, B, m_b, V_b = _closure_inputs(g)
+    assert B.shape[0] == B.shape[1]
+    m, V = B @ m_b, B @ V_b @ B.T
+    V = (V + V.T) / 2
+    loss, grad, parts = orc.mstep_closure_cholesky(
+        thd(g["theta"]), LOWER, UPPER, int(g["n_px"]), X, r, m, V,
+        float(g["logA"]), float(g["lambda0"]), want_parts=True)
+    assert abs(loss - float(g["loss"])) <= 1e-10 * abs(float(g["loss"]))
+    assert abs(parts["KL"] - float(g["KL"])) <= 1e-10 * abs(float(g["KL"]))
+    gv = np.array([grad[k] for k in KEYS])
+    assert relerr(gv, g["grad"]) < 1e-7
+    assert relerr(parts["lam_m"], g["lam_m"]) < 1e-10
+    assert relerr(parts["lam_var"], g["lam_var"]) < 1e-9
+
+
+def test_closure_out_of_box_returns_inf():
+    th = syn.theta_eval()
+    th["Amp"] = -0.1
+    X = T(syn.stimuli(8, 16))
+    loss, grad = orc.mstep_closure_cholesky(th, LOWER, UPPER, 4, X, X[:, 0], X[:, 0], torch.eye(8, dtype=torch.float64), 0.0, 0.0)
+    assert loss == float("inf") and all(v == float("inf") for v in grad.values())
+
+
+def test_g4_estep():
+    g = load_golden("g4_estep_N64.npz")
+    B, ev = T(g["B"]), T(g["eigvals"])
+    m_b = B.T @ T(g["m"])
+    m_new_b, V_new_b = orc.newton_estep(T(g["r"]), B, m_b, float(g["logA"]), T(g["f"]), torch.diag(ev))
+    assert relerr(m_new_b, g["m_new_b"]) < 1e-10
+    assert relerr(V_new_b, g["V_new_b"]) < 1e-10
+    m_new, V_new = orc.estep_cholesky(T(g["Kt"]), T(g["r"]), T(g["m"]), T(g["f"]), float(g["logA"]))
+    assert relerr(m_new, g["m_new"]) < 1e-9
+    assert relerr(V_new, g["V_new"]) < 1e-9
+
+
+def test_g5_predict():
+    g = load_golden("g5_predict_N64.npz")
+    th = thd(g["theta"])
+    C, mask = orc.spatial_metric(th, LOWER, UPPER, 8)
+    X, Xs = T(g["X"])[:, mask], T(g["Xstar"])[:, mask]
+    Kt = orc.arccos_gram(th, X, X, C)
+    ev, evec, keep = orc.eigen_basis(Kt, 1e-14)
+    B = evec
+    m_b, V_b = B.T @ T(g["m"]), B.T @ T(g["V"]) @ B
+    mu, s2 = orc.predict_moments(th, Xs, X, C, torch.diag(ev), torch.diag(1 / ev), m_b, V_b, B)
+    assert relerr(mu, g["mu"]) < 1e-10 and relerr(s2, g["s2"]) < 1e-9
+    assert relerr(orc.predict_rate(float(g["logA"]), float(g["lambda0"]), mu, s2), g["rate"]) < 1e-10
+    mu2, s22 = orc.predict_cholesky(th, Xs, X, C, Kt, T(g["m"]), T(g["V"]))
+    assert relerr(mu2, g["mu"]) < 1e-9 and relerr(s22, g["s2"]) < 1e-8
+
+
+def test_g7_moments_gradients_notebook_known_answers():
+    """Hand-typed from the saved outputs of the reference's moments_gradients.ipynb
+    (cells 1-3): pins latent_moments / expected_loglik / kl_divergence gradient algebra
+    independently of any import of the reference."""
+    a_mat = T([[1., 2, 3, 4], [5, 6, 7, 8], [9, 10, 11, 12]])
+    Sigma = T([[1., 2, 3], [5, 6, 7], [8, 7, 6]])
+    dSigma = T([[4., 5, 6], [5, 6, 7], [6, 7, 8]])
+    Sigma = Sigma + Sigma.T
+    dSigma = dSigma + dSigma.T
+    m = T([1., 2, 3])
+    dki = T([[6., 7, 8, 9], [2, 3, 4, 5], [9, 8, 7, 6]])
+    dkstar = T([3., 4, 5, 6])
+    invV = Sigma * 3
+    a, K, dK = a_mat.T.contiguous(), dki.T.contiguous(), dki.T.contiguous()
+    Kt_inv = torch.linalg.pinv(Sigma)
+    V = torch.linalg.inv(invV)
+    lam_m, lam_var, dlm, dlv = orc.latent_moments(a, K, torch.zeros(4, dtype=torch.float64), m, V,
+                                                  {"p": dK}, {"p": dSigma}, {"p": dkstar}, Kt_inv)
+    assert np.allclose(dlm["p"].numpy(), [13.75, 19.9167, 26.0833, 32.25], atol=5e-5)
+    assert np.allclose(dlv["p"].numpy(), [-2199.1944, -3161.6944, -4291.75, -5589.3611], atol=5e-5)
+    f = T([55., 4, 22, 5])
+    r = T([23., 47, 2, 1])
+    L, dL = orc.expected_loglik(r, f, T([1., 2, 3, 4]), lam_var, 0.0, 0.0, dlm, dlv)
+    assert float(L) == 41.0
+    assert abs(float(dL["p"]) - 127749.63888888987) < 1e-6
+    # KL: the notebook shifts both matrices by 10*I inside log_det only
+    c = V @ Kt_inv
+    b = Kt_inv @ m
+    eye = torch.eye(3, dtype=torch.float64)
+    KLD = (-0.5 * (orc.chol_logdet(V + 10 * eye) - orc.chol_logdet(Sigma + 10 * eye))
+           + 0.5 * (m @ b) + 0.5 * torch.trace(c))
+    assert abs(float(KLD) - 34.91913283450331) < 1e-10
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        try:
+            _, dKL = orc.kl_divergence(m, V, Sigma, Kt_inv, {"p": dSigma}, quiet=True)
+        except ValueError:  # Sigma is indefinite: guarded_log raises exactly as safe_log would
+            Bp = dSigma @ Kt_inv
+            dKL = {"p": 0.5 * torch.trace(Bp) - 0.5 * torch.trace(c @ Bp) - 0.5 * (b @ (Bp @ m))}
+    assert abs(float(dKL["p"]) - 110.47222222222383) < 1e-9
+
+
+def test_logdet_fallback_paths():
+    M = torch.diag(T([4.0, 1e-6, 2.0]))
+    M[1, 1] = -1.0  # symmetric, indefinite -> eigen fallback over kept eigenvalues
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        v = orc.chol_logdet(M)
+    assert abs(float(v) - np.log(8.0)) < 1e-12 and len(w) >= 1
+    A = T([[1.0, 2.0], [0.0, -1.0]])
+    with warnings.catch_warnings(record=True):
+        warnings.simplefilter("always")
+        assert float(orc.chol_logdet(A)) == 0.0
+    with pytest.raises(ValueError):
+        orc.guarded_log(T([1e-12]))
