@@ -1,0 +1,78 @@
+// Shared declarations for the MI355X (gfx950) GP-fit library.  Internal header.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+
+namespace gpfit {
+
+// float32-rounded pi: the reference overwrites torch.pi before switching the default
+// dtype to float64 (reference utils.py:25 vs :33), so every pi in its kernel is this value.
+constexpr double PI32 = 3.1415927410125732;
+
+constexpr int TILE = 128;  // GEMM block tile (M and N) and Cholesky leaf size
+constexpr int KTILE = 16;  // GEMM K step staged through LDS
+
+void set_error(const std::string& msg);
+
+#define GP_HIP(expr)                                                                     \
+  do {                                                                                   \
+    hipError_t _e = (expr);                                                              \
+    if (_e != hipSuccess) {                                                              \
+      gpfit::set_error(std::string(#expr) + ": " + hipGetErrorString(_e));               \
+      return -100;                                                                       \
+    }                                                                                    \
+  } while (0)
+
+inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
+
+// ---- fp64 MFMA GEMM -------------------------------------------------------------
+// C[M,N] = alpha * op(A)[M,K] * op(B)[K,N] + beta * C        (row-major storage)
+//   a_kmajor = 0 : A stored [M][K] (k contiguous)   element (m,k) at A[m*lda + k]
+//   a_kmajor = 1 : A stored [K][M] (m contiguous)   element (m,k) at A[k*lda + m]
+//   b_kmajor = 1 : B stored [K][N] (n contiguous)   element (k,n) at B[k*ldb + n]
+//   b_kmajor = 0 : B stored [N][K] (k contiguous)   element (k,n) at B[n*ldb + k]
+// Triangular structure is exploited per 128-tile:
+//   out_lower   : only tiles with tj <= ti are computed / written (M == N)
+//   a_tri/b_tri : 0 dense, 1 op() is lower triangular, 2 op() is upper triangular
+//                 (restricts each tile's k range; the skipped part must hold zeros or is
+//                  simply never read)
+// K must be a multiple of 16; M, N arbitrary (edges are predicated); lda/ldb/ldc even.
+struct GemmArgs {
+  const double* A;
+  const double* B;
+  double* C;
+  int64_t lda, ldb, ldc;
+  int M, N, K;
+  double alpha, beta;
+  int a_kmajor, b_kmajor;
+  int out_lower;
+  int a_tri, b_tri;
+  int batch;                 // number of independent problems (grid.y)
+  int64_t sA, sB, sC;        // batch strides (elements)
+  int split_k;               // >1: partial products written to C + z*sC (beta ignored)
+};
+int launch_gemm(const GemmArgs& a, hipStream_t s);
+
+// Arc-cosine Gram matrix from the k-major, zero-padded operands XCt[Kd][ld1], Xt[Kd][ld2]:
+//   G = XCt^T Xt + s0^2 ; c = clip(G/(q1 q2 + 1e-7)) ; K = q1 q2 J(c)
+// np1/np2: padded extents (multiples of 128) that the loads may touch; nv1/nv2: valid
+// extents that are stored.  `lower`: only tiles on/below the diagonal (square case).
+// `pad_identity`: rows/cols >= nv get the identity (Kout must then hold np1 x np2).
+struct GramArgs {
+  const double* XCt;
+  const double* Xt;
+  const double* q1;   // [np1]
+  const double* q2;   // [np2]
+  double* Kout;       // [..][ldk]
+  double* Cos;        // same shape as Kout, or nullptr
+  int64_t ld1, ld2, ldk;
+  int np1, np2, nv1, nv2, Kd;
+  double s0sq;
+  int lower;
+  int pad_identity;
+};
+int launch_gram(const GramArgs& a, hipStream_t s);
+
+}  // namespace gpfit

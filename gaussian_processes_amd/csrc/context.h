@@ -1,0 +1,51 @@
+// Workspace context of the GP fit library.  Internal header.
+#pragma once
+#include "kernels.h"
+#include <vector>
+
+struct gpfit_ctx {
+  int device = 0;
+  int np_cap = 0, dp_cap = 0, dfull_cap = 0;
+  hipStream_t aux = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+
+  // N x N work matrices (each np_cap^2 doubles)
+  double *Kbuf = nullptr, *Cos = nullptr, *Lbuf = nullptr, *Libuf = nullptr, *Vbuf = nullptr, *LVbuf = nullptr,
+         *LiVbuf = nullptr, *Tbuf = nullptr, *Zbuf = nullptr, *Wbuf = nullptr, *Abuf = nullptr, *Tmp = nullptr,
+         *TmpV = nullptr;
+  // N x d / d x d
+  double *Xt = nullptr, *Xm = nullptr, *XCt = nullptr, *Cmat = nullptr, *Ybuf = nullptr, *Mpart = nullptr,
+         *Mmat = nullptr;
+  // vectors (np_cap each unless noted)
+  double *Kvec = nullptr, *q = nullptr, *lam_m = nullptr, *lam_var = nullptr, *fvec = nullptr, *wl = nullptr,
+         *yv = nullptr, *bv = nullptr, *tvec = nullptr /* 2 np */, *mpad = nullptr, *rpad = nullptr;
+  double *upart = nullptr, *vpart = nullptr, *sumA_part = nullptr, *frob_part = nullptr, *trmv_part = nullptr;
+  double* scal = nullptr;       // device scalars [64]
+  double* scal_host = nullptr;  // pinned [64]
+  int* pix = nullptr;           // device [dfull_cap]
+  int* pix_host = nullptr;      // pinned
+  int* info = nullptr;          // device [4]
+  int* info_host = nullptr;     // pinned [4]
+  std::vector<void*> allocs;
+  int split_k_M = 32;
+
+  // cached state of the last upload / evaluation (used by estep / predict entry points)
+  int cur_n = 0, cur_np = 0, cur_d = 0, cur_dp = 0;
+};
+
+namespace gpfit {
+
+struct CholBufs {
+  double* A;    // input, lower triangle; destroyed
+  double* L;    // output factor
+  double* Li;   // output inverse blocks (full inverse when need_inv at the top)
+  double* Tmp;  // scratch, same shape
+  int64_t ld;
+  int* info;
+};
+// Recursive blocked Cholesky of the n x n diagonal block at offset r0 (n a multiple of 128),
+// built entirely from the MFMA GEMM and the 128 x 128 leaf.  With need_inv the full inverse of
+// the factor is assembled on the way (L^-1 costs n^3/3 more; without it only n^3/12).
+int potrf_rec(const CholBufs& B, int r0, int n, bool need_inv, hipStream_t s);
+
+}  // namespace gpfit

@@ -1,0 +1,516 @@
+// Element-wise / reduction kernels of the GP fit path (everything that is not an MFMA GEMM
+// or the Cholesky leaf).  All of them are HBM- or latency-bound and tiny next to the N^3
+// work; they are written for coalesced access and deterministic (atomic-free) reductions.
+#include "kernels.h"
+
+namespace gpfit {
+
+// ------------------------------------------------------------------ helpers
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
+  return v;
+}
+
+// Sum over the whole block; result valid in every thread.  sh: >= 17 doubles.
+__device__ __forceinline__ double block_sum(double v, double* sh) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nw = (blockDim.x + 63) >> 6;
+  v = wave_sum(v);
+  __syncthreads();
+  if (lane == 0) sh[wave] = v;
+  __syncthreads();
+  if (wave == 0) {
+    double t = (lane < nw) ? sh[lane] : 0.0;
+    t = wave_sum(t);
+    if (lane == 0) sh[16] = t;
+  }
+  __syncthreads();
+  return sh[16];
+}
+
+// torch.linspace(-1, 1, n)[i] in fp64: two-sided fused form (matches ATen bit for bit;
+// the pixel mesh of reference utils.py:876).
+__device__ __forceinline__ double lin_pm1(int i, int n) {
+  if (n <= 1) return -1.0;
+  const double step = 2.0 / (double)(n - 1);
+  return (i < n / 2) ? fma(step, (double)i, -1.0) : fma(-step, (double)(n - 1 - i), 1.0);
+}
+
+// ------------------------------------------------------------------ localker
+__global__ void localker_kernel(Theta th, const int* __restrict__ pix, int d, int dp, int n_rows, int n_cols,
+                                double* __restrict__ C, int64_t ldc, double* __restrict__ dC) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = blockIdx.y * blockDim.y + threadIdx.y;
+  if (i >= dp || j >= dp) return;
+  if (i >= d || j >= d) {
+    C[(int64_t)i * ldc + j] = 0.0;
+    return;
+  }
+  const int pi = pix[i], pj = pix[j];
+  const double xi = lin_pm1(pi % n_cols, n_cols), yi = lin_pm1(pi / n_cols, n_rows);
+  const double xj = lin_pm1(pj % n_cols, n_cols), yj = lin_pm1(pj / n_cols, n_rows);
+  const double dxi = xi - th.eps0x, dyi = yi - th.eps0y, dxj = xj - th.eps0x, dyj = yj - th.eps0y;
+  const double lai = -th.eb * (dxi * dxi + dyi * dyi);  // utils.py:880
+  const double laj = -th.eb * (dxj * dxj + dyj * dyj);
+  const double ai = exp(lai), aj = exp(laj);            // :881
+  const double ex = xj - xi, ey = yj - yi;
+  const double ls = -th.er * (ex * ex + ey * ey);       // :890
+  const double es = exp(ls);                            // :892
+  const double cij = th.amp * ai * es * aj;             // :895
+  const double cji = th.amp * aj * es * ai;
+  const double c = (cij + cji) / 2.0;                   // :898
+  C[(int64_t)i * ldc + j] = c;
+  if (dC) {
+    const int64_t dd = (int64_t)d * d, o = (int64_t)i * d + j;
+    dC[o] = c / th.amp;                                           // Amp        :902
+    dC[dd + o] = c * (lai + laj);                                 // -2log2beta :907
+    dC[2 * dd + o] = c * ls;                                      // -log2rho2  :909
+    dC[3 * dd + o] = 2.0 * th.eb * c * (xi + xj - 2.0 * th.eps0x);  // eps_0x   :904
+    dC[4 * dd + o] = 2.0 * th.eb * c * (yi + yj - 2.0 * th.eps0y);  // eps_0y   :905
+  }
+}
+
+int launch_localker(const Theta& th, const int* pix, int d, int dp, int n_rows, int n_cols, double* C,
+                    int64_t ldc, double* dC, hipStream_t s) {
+  dim3 block(32, 8), grid((dp + 31) / 32, (dp + 7) / 8);
+  hipLaunchKernelGGL(localker_kernel, grid, block, 0, s, th, pix, d, dp, n_rows, n_cols, C, ldc, dC);
+  GP_HIP(hipGetLastError());
+  return 0;
+}
+
+// ------------------------------------------------------------------ gather / transpose
+__global__ void gather_kernel(const double* __restrict__ X, int64_t ldx, int n, const int* __restrict__ pix,
+                              int d, double* __restrict__ Xt, int64_t ldt, double* __restrict__ Xm,
+                              int64_t ldm) {
+  __shared__ double tile[32][33];
+  const int k0 = blockIdx.x * 32, n0 = blockIdx.y * 32;
+  const int tx = threadIdx.x, ty = threadIdx.y;  // 32 x 8
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int nn = n0 + ty + 8 * r, k = k0 + tx;
+    double v = 0.0;
+    if (nn < n && k < d) v = X[(int64_t)nn * ldx + pix[k]];
+    tile[ty + 8 * r][tx] = v;
+    if (Xm) Xm[(int64_t)nn * ldm + k] = v;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int k = k0 + ty + 8 * r, nn = n0 + tx;
+    Xt[(int64_t)k * ldt + nn] = tile[tx][ty + 8 * r];
+  }
+}
+
+int launch_gather(const double* X, int64_t ldx, int n, const int* pix, int d, int dp, int np, double* Xt,
+                  int64_t ldt, double* Xm, int64_t ldm, hipStream_t s) {
+  if (dp % 32 || np % 32) {
+    set_error("launch_gather: padded extents must be multiples of 32");
+    return -3;
+  }
+  hipLaunchKernelGGL(gather_kernel, dim3(dp / 32, np / 32), dim3(32, 8), 0, s, X, ldx, n, pix, d, Xt, ldt, Xm,
+                     ldm);
+  GP_HIP(hipGetLastError());
+  return 0;
+}
+
+// ------------------------------------------------------------------ q / Kvec
+__global__ void qvec_kernel(const double* __restrict__ Xt, const double* __restrict__ XCt, int64_t ld, int dp,
+                            int n, int np, double s0sq, double* __restrict__ Kvec, double* __restrict__ q) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= np) return;
+  if (i >= n) {
+    Kvec[i] = 1.0;
+    q[i] = 1.0;
+    return;
+  }
+  double h = 0.0;
+  for (int k = 0; k < dp; ++k) h += Xt[(int64_t)k * ld + i] * XCt[(int64_t)k * ld + i];
+  const double kv = h + s0sq;  // utils.py:1029
+  Kvec[i] = kv;
+  q[i] = sqrt(kv);             // utils.py:978
+}
+
+int launch_qvec(const double* Xt, const double* XCt, int64_t ld, int dp, int n, int np, double s0sq,
+                double* Kvec, double* q, hipStream_t s) {
+  hipLaunchKernelGGL(qvec_kernel, dim3((np + 255) / 256), dim3(256), 0, s, Xt, XCt, ld, dp, n, np, s0sq, Kvec, q);
+  GP_HIP(hipGetLastError());
+  return 0;
+}
+
+// ------------------------------------------------------------------ pack / symmetrize
+__global__ void pack_lower_kernel(const double* __restrict__ src, int64_t lds, int n, double* __restrict__ dst,
+                                  int64_t ldd) {
+  const int tj = blockIdx.x, ti = blockIdx.y;
+  if (tj > ti) return;
+  const int r0 = ti * TILE, c0 = tj * TILE;
+  for (int e = threadIdx.x; e < TILE * TILE; e += blockDim.x) {
+    const int i = r0 + (e >> 7), j = c0 + (e & 127);
+    double v;
+    if (i < n && j < n) v = src[(int64_t)i * lds + j];
+    else v = (i == j) ? 1.0 : 0.0;
+    dst[(int64_t)i * ldd + j] = v;
+  }
+}
+
+int launch_pack_lower(const double* src, int64_t lds, int n, double* dst, int64_t ldd, int np, hipStream_t s) {
+  hipLaunchKernelGGL(pack_lower_kernel, dim3(np / TILE, np / TILE), dim3(256), 0, s, src, lds, n, dst, ldd);
+  GP_HIP(hipGetLastError());
+  return 0;
+}
+
+__global__ void symmetrize_kernel(double* __restrict__ A, int64_t lda, int n) {
+  __shared__ double tile[32][33];
+  const int tj = blockIdx.x, ti = blockIdx.y;
+  if (tj > ti) return;
+  const int tx = threadIdx.x, ty = threadIdx.y;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int i = ti * 32 + ty + 8 * r, j = tj * 32 + tx;
+    tile[ty + 8 * r][tx] = (i < n && j < n) ? A[(int64_t)i * lda + j] : 0.0;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    // element (jj, ii) of the upper triangle <- (ii, jj) of the lower one
+    const int jj = tj * 32 + ty + 8 * r, ii = ti * 32 + tx;
+    if (ii < n && jj < n && ii > jj) A[(int64_t)jj * lda + ii] = tile[tx][ty + 8 * r];
+  }
+}
+
+int launch_symmetrize(double* A, int64_t lda, int n, hipStream_t s) {
+  const int t = (n + 31) / 32;
+  hipLaunchKernelGGL(symmetrize_kernel, dim3(t, t), dim3(32, 8), 0, s, A, lda, n);
+  GP_HIP(hipGetLastError());
+  return 0;
+}
+
+// ------------------------------------------------------------------ small reductions
+__global__ void logdet_kernel(const double* __restrict__ L, int64_t ldl, int n, double* __restrict__ out) {
+  __shared__ double sh[17];
+  double v = 0.0;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) v += log(L[(int64_t)i * ldl + i]);
+  v = block_sum(v, sh);
+  if (threadIdx.x == 0) out[0] = 2.0 * v;  // utils.py:1278
+}
+
+int launch_logdet(const double* L, int64_t ldl, int n, double* out, hipStream_t s) {
+  hipLaunchKernelGGL(logdet_kernel, dim3(1), dim3(1024), 0, s, L, ldl, n, out);
+  GP_HIP(hipGetLastError());
+  return 0;
+}
+
+__global__ void sum_kernel(const double* __restrict__ x, int n, double scale, double* __restrict__ out) {
+  __shared__ double sh[17];
+  double v = 0.0;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) v += x[i];
+  v = block_sum(v, sh);
+  if (threadIdx.x == 0) out[0] = scale * v;
+}
+
+__global__ void frob_tile_kernel(const double* __restrict__ T, int64_t ldt, double* __restrict__ partial) {
+  __shared__ double sh[17];
+  int ti, tj;
+  {
+    const int t = blockIdx.x;
+    int i = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
+    while ((i + 1) * (i + 2) / 2 <= t) ++i;
+    while (i * (i + 1) / 2 > t) --i;
+    ti = i;
+    tj = t - i * (i + 1) / 2;
+  }
+  const double* base = T + (int64_t)ti * TILE * ldt + tj * TILE;
+  double v = 0.0;
+  for (int e = threadIdx.x; e < TILE * TILE / 2; e += blockDim.x) {
+    const int i = e >> 6, j = (e & 63) * 2;
+    const double2 x = *reinterpret_cast<const double2*>(base + (int64_t)i * ldt + j);
+    v += x.x * x.x + x.y * x.y;
+  }
+  v = block_sum(v, sh);
+  if (threadIdx.x == 0) partial[blockIdx.x] = v;
+}
+
+int launch_frob_lower(const double* T, int64_t ldt, int np, double* out, double* partial, hipStream_t s) {
+  const int t = np / TILE, nt = t * (t + 1) / 2;
+  hipLaunchKernelGGL(frob_tile_kernel, dim3(nt), dim3(256), 0, s, T, ldt, partial);
+  hipLaunchKernelGGL(sum_kernel, dim3(1), dim3(1024), 0, s, partial, nt, 1.0, out);
+  GP_HIP(hipGetLastError());
+  return 0;
+}
+
+__global__ void trmv_lower_kernel(const double* __restrict__ L, int64_t ldl, int np, const double* __restrict__ x,
+                                  double* __restrict__ y) {
+  const int lane = threadIdx.x & 63;
+  const int i = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (i >= np) return;
+  const double* row = L + (int64_t)i * ldl;
+  double v = 0.0;
+  for (int j = lane; j <= i; j += 64) v += row[j] * x[j];
+  v = wave_sum(v);
+  if (lane == 0) y[i] = v;
+}
+
+int launch_trmv_lower(const double* L, int64_t ldl, int np, const double* x, double* y, hipStream_t s) {
+  hipLaunchKernelGGL(trmv_lower_kernel, dim3((np + 3) / 4), dim3(256), 0, s, L, ldl, np, x, y);
+  GP_HIP(hipGetLastError());
+  return 0;
+}
+
+// z_j = sum_{i >= j} L[i][j] x_i : block = 64 columns x one chunk of 512 rows
+__global__ void trmv_lower_t_kernel(const double* __restrict__ L, int64_t ldl, int np,
+                                    const double* __restrict__ x, double* __restrict__ partial) {
+  __shared__ double sh[4][64];
+  const int c = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int j = blockIdx.x * 64 + c;
+  const int i0 = blockIdx.y * 512, i1 = min(np, i0 + 512);
+  double v = 0.0;
+  if (i1 > blockIdx.x * 64) {
+    for (int i = i0 + rl; i < i1; i += 4)
+      if (i >= j) v += L[(int64_t)i * ldl + j] * x[i];
+  }
+  sh[rl][c] = v;
+  __syncthreads();
+  if (rl == 0) partial[(int64_t)blockIdx.y * np + j] = sh[0][c] + sh[1][c] + sh[2][c] + sh[3][c];
+}
+
+__global__ void reduce_slices_kernel(const double* __restrict__ src, int64_t stride, int nslice,
+                                     double* __restrict__ dst, int64_t count) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  double v = 0.0;
+  for (int z = 0; z < nslice; ++z) v += src[(int64_t)z * stride + i];
+  dst[i] = v;
+}
+
+int launch_reduce_slices(const double* src, int64_t slice_stride, int nslice, double* dst, int64_t count,
+                         hipStream_t s) {
+  hipLaunchKernelGGL(reduce_slices_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, s, src,
+                     slice_stride, nslice, dst, count);
+  GP_HIP(hipGetLastError());
+  return 0;
+}
+
+int launch_trmv_lower_t(const double* L, int64_t ldl, int np, const double* x, double* z, double* partial,
+                        hipStream_t s) {
+  const int chunks = (np + 511) / 512;
+  hipLaunchKernelGGL(trmv_lower_t_kernel, dim3(np / 64, chunks), dim3(256), 0, s, L, ldl, np, x, partial);
+  GP_HIP(hipGetLastError());
+  return launch_reduce_slices(partial, np, chunks, z, np, s);
+}
+
+__global__ void dot_kernel(const double* __restrict__ x, const double* __restrict__ y, int n,
+                           double* __restrict__ out) {
+  __shared__ double sh[17];
+  double v = 0.0;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) v += x[i] * y[i];
+  v = block_sum(v, sh);
+  if (threadIdx.x == 0) out[0] = v;
+}
+
+int launch_dot(const double* x, const double* y, int n, double* out, hipStream_t s) {
+  hipLaunchKernelGGL(dot_kernel, dim3(1), dim3(1024), 0, s, x, y, n, out);
+  GP_HIP(hipGetLastError());
+  return 0;
+}
+
+// ------------------------------------------------------------------ moments / rate / likelihood
+__global__ void moments_kernel(const double* __restrict__ Kvec, const double* __restrict__ q,
+                               const double* __restrict__ Cos, int64_t ldc, const double* __restrict__ V,
+                               int64_t ldv, const double* __restrict__ m, const double* __restrict__ r, int n,
+                               double A, double lambda0, double* __restrict__ lam_m,
+                               double* __restrict__ lam_var, double* __restrict__ f, double* __restrict__ wl,
+                               double* __restrict__ scal) {
+  __shared__ double sh[17];
+  double s_rm = 0.0, s_r = 0.0, s_f = 0.0;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    const double c = Cos[(int64_t)i * ldc + i];
+    const double delta = acos(c);
+    const double J = (sqrt(1.0 - c * c) + PI32 * c - delta * c) / PI32;
+    const double kii = q[i] * q[i] * J;                     // K~_ii as the Gram kernel wrote it
+    const double lv = Kvec[i] - kii + V[(int64_t)i * ldv + i];  // utils.py:1101 with a = B, full rank
+    const double lm = m[i];                                 // utils.py:1090
+    const double fi = exp(A * lm + 0.5 * A * A * lv + lambda0);  // utils.py:1138
+    const double g = 1.0 - J - (PI32 - delta) * (1.0 - c) / PI32;
+    lam_m[i] = lm;
+    lam_var[i] = lv;
+    f[i] = fi;
+    wl[i] = -0.5 * A * A * fi * g;
+    s_rm += r[i] * lm;
+    s_r += r[i];
+    s_f += fi;
+  }
+  s_rm = block_sum(s_rm, sh);
+  s_r = block_sum(s_r, sh);
+  s_f = block_sum(s_f, sh);
+  if (threadIdx.x == 0) {
+    scal[0] = s_rm;
+    scal[1] = s_r;
+    scal[2] = s_f;
+  }
+}
+
+int launch_moments(const double* Kvec, const double* q, const double* Cos, int64_t ldc, const double* V,
+                   int64_t ldv, const double* m, const double* r, int n, double A, double lambda0,
+                   double* lam_m, double* lam_var, double* f, double* wl, double* scal, hipStream_t s) {
+  hipLaunchKernelGGL(moments_kernel, dim3(1), dim3(1024), 0, s, Kvec, q, Cos, ldc, V, ldv, m, r, n, A, lambda0,
+                     lam_m, lam_var, f, wl, scal);
+  GP_HIP(hipGetLastError());
+  return 0;
+}
+
+// ------------------------------------------------------------------ adjoint pass (64 x 64 tiles)
+__global__ __launch_bounds__(256) void adjoint_kernel(const double* __restrict__ W, const double* __restrict__ Cos,
+                                                      int64_t ld, const double* __restrict__ b,
+                                                      const double* __restrict__ q, int n, int np,
+                                                      double* __restrict__ Aout, double* __restrict__ upart,
+                                                      double* __restrict__ vpart, double* __restrict__ sumA_part) {
+  __shared__ double tA[64][65];
+  __shared__ double colsum[4][64];
+  __shared__ double sh[17];
+  int ti, tj;
+  {
+    const int t = blockIdx.x;
+    int i = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
+    while ((i + 1) * (i + 2) / 2 <= t) ++i;
+    while (i * (i + 1) / 2 > t) --i;
+    ti = i;
+    tj = t - i * (i + 1) / 2;
+  }
+  const bool diag = (ti == tj);
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;  // ty = wave
+  const int j = tj * 64 + tx;
+  const double qj = q[j], bj = b[j];
+  double csum = 0.0, asum = 0.0;
+  for (int rr = ty; rr < 64; rr += 4) {
+    const int i = ti * 64 + rr;
+    double aw = 0.0, bm = 0.0;
+    if (i < n && j < n) {
+      // canonical storage is the lower triangle: in a diagonal tile read (j,i) when i < j
+      const int64_t o = (diag && i < j) ? ((int64_t)j * ld + i) : ((int64_t)i * ld + j);
+      const double w = W[o] - 0.5 * b[i] * bj;
+      const double c = Cos[o];
+      aw = w * (PI32 - acos(c)) / PI32;
+      bm = w * sqrt(1.0 - c * c) / PI32;
+    }
+    tA[rr][tx] = aw;
+    Aout[(int64_t)i * ld + j] = aw;
+    asum += aw;
+    // row sum over the 64 columns of this tile (one wave holds a whole row)
+    const double rs = wave_sum(bm * qj);
+    if (tx == 0) upart[(int64_t)tj * np + i] = rs;
+    csum += bm * q[i];
+  }
+  colsum[ty][tx] = csum;
+  __syncthreads();
+  if (!diag) {
+    if (ty == 0) vpart[(int64_t)ti * np + j] = colsum[0][tx] + colsum[1][tx] + colsum[2][tx] + colsum[3][tx];
+    // mirrored tile: Aout[j][i] = Aw[i][j]
+    for (int rr = ty; rr < 64; rr += 4) {
+      const int jj = tj * 64 + rr, ii = ti * 64 + tx;
+      Aout[(int64_t)jj * ld + ii] = tA[tx][rr];
+    }
+  }
+  asum = block_sum(asum, sh);
+  if (threadIdx.x == 0) sumA_part[blockIdx.x] = diag ? asum : 2.0 * asum;
+}
+
+__global__ void adjoint_u_kernel(const double* __restrict__ upart, const double* __restrict__ vpart, int nt64,
+                                 const double* __restrict__ q, const double* __restrict__ wl, int n, int np,
+                                 double* __restrict__ tvec, double* __restrict__ uq) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= np) return;
+  if (i >= n) {
+    tvec[i] = 0.0;
+    uq[i] = 0.0;
+    return;
+  }
+  const int T = i >> 6;
+  double u = 0.0;
+  for (int t = 0; t <= T; ++t) u += upart[(int64_t)t * np + i];
+  for (int t = T + 1; t < nt64; ++t) u += vpart[(int64_t)t * np + i];
+  const double v = u / q[i];
+  uq[i] = v;
+  tvec[i] = v - wl[i];
+}
+
+int launch_adjoint(const double* W, const double* Cos, int64_t ld, const double* b, const double* q, int n,
+                   int np, double* Aout, double* upart, double* vpart, double* sumA_part, hipStream_t s) {
+  const int t = np / 64, nt = t * (t + 1) / 2;
+  hipLaunchKernelGGL(adjoint_kernel, dim3(nt), dim3(256), 0, s, W, Cos, ld, b, q, n, np, Aout, upart, vpart,
+                     sumA_part);
+  GP_HIP(hipGetLastError());
+  return 0;
+}
+
+int launch_adjoint_reduce(const double* upart, const double* vpart, const double* sumA_part, int ntile,
+                          int ntile_tri, const double* q, const double* wl, int n, int np, double* tvec,
+                          double* scal_out, hipStream_t s) {
+  // uq is staged in the (now consumed) first row of upart's tail: caller provides tvec[np..2np)
+  double* uq = tvec + np;
+  hipLaunchKernelGGL(adjoint_u_kernel, dim3((np + 255) / 256), dim3(256), 0, s, upart, vpart, ntile, q, wl, n,
+                     np, tvec, uq);
+  hipLaunchKernelGGL(sum_kernel, dim3(1), dim3(1024), 0, s, uq, n, 1.0, scal_out + 0);
+  hipLaunchKernelGGL(sum_kernel, dim3(1), dim3(1024), 0, s, wl, n, 1.0, scal_out + 1);
+  hipLaunchKernelGGL(sum_kernel, dim3(1), dim3(1024), 0, s, sumA_part, ntile_tri, 1.0, scal_out + 2);
+  GP_HIP(hipGetLastError());
+  return 0;
+}
+
+__global__ void rowscale_add_kernel(double* __restrict__ Y, int64_t ldy, const double* __restrict__ Xm,
+                                    int64_t ldm, const double* __restrict__ t, int dp) {
+  const int i = blockIdx.y;
+  const double ti = t[i];
+  for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < dp; k += gridDim.x * blockDim.x)
+    Y[(int64_t)i * ldy + k] += ti * Xm[(int64_t)i * ldm + k];
+}
+
+int launch_rowscale_add(double* Y, int64_t ldy, const double* Xm, int64_t ldm, const double* t, int np,
+                        int dp, hipStream_t s) {
+  hipLaunchKernelGGL(rowscale_add_kernel, dim3((dp + 255) / 256, np), dim3(256), 0, s, Y, ldy, Xm, ldm, t, dp);
+  GP_HIP(hipGetLastError());
+  return 0;
+}
+
+// ------------------------------------------------------------------ metric contraction
+// grad5[p] = sum_kl dC_p[k][l] M[k][l], dC_p rebuilt from C and the pixel coordinates
+// (utils.py:902-909), order Amp, -2log2beta, -log2rho2, eps_0x, eps_0y.
+__global__ void metric_contract_kernel(Theta th, const int* __restrict__ pix, int d, int n_rows, int n_cols,
+                                       const double* __restrict__ C, int64_t ldc, const double* __restrict__ M,
+                                       int64_t ldm, double* __restrict__ grad5) {
+  __shared__ double sh[17];
+  double g[5] = {0, 0, 0, 0, 0};
+  const int64_t total = (int64_t)d * d;
+  for (int64_t e = threadIdx.x; e < total; e += blockDim.x) {
+    const int i = (int)(e / d), j = (int)(e % d);
+    const int pi = pix[i], pj = pix[j];
+    const double xi = lin_pm1(pi % n_cols, n_cols), yi = lin_pm1(pi / n_cols, n_rows);
+    const double xj = lin_pm1(pj % n_cols, n_cols), yj = lin_pm1(pj / n_cols, n_rows);
+    const double dxi = xi - th.eps0x, dyi = yi - th.eps0y, dxj = xj - th.eps0x, dyj = yj - th.eps0y;
+    const double lai = -th.eb * (dxi * dxi + dyi * dyi);
+    const double laj = -th.eb * (dxj * dxj + dyj * dyj);
+    const double ex = xj - xi, ey = yj - yi;
+    const double ls = -th.er * (ex * ex + ey * ey);
+    const double c = C[(int64_t)i * ldc + j];
+    const double mm = M[(int64_t)i * ldm + j];
+    g[0] += (c / th.amp) * mm;
+    g[1] += (c * (lai + laj)) * mm;
+    g[2] += (c * ls) * mm;
+    g[3] += (2.0 * th.eb * c * (xi + xj - 2.0 * th.eps0x)) * mm;
+    g[4] += (2.0 * th.eb * c * (yi + yj - 2.0 * th.eps0y)) * mm;
+  }
+#pragma unroll
+  for (int p = 0; p < 5; ++p) {
+    const double v = block_sum(g[p], sh);
+    if (threadIdx.x == 0) grad5[p] = v;
+  }
+}
+
+int launch_metric_contract(const Theta& th, const int* pix, int d, int n_rows, int n_cols, const double* C,
+                           int64_t ldc, const double* M, int64_t ldm, double* grad5, hipStream_t s) {
+  hipLaunchKernelGGL(metric_contract_kernel, dim3(1), dim3(1024), 0, s, th, pix, d, n_rows, n_cols, C, ldc, M,
+                     ldm, grad5);
+  GP_HIP(hipGetLastError());
+  return 0;
+}
+
+}  // namespace gpfit

@@ -1,0 +1,99 @@
+// General fp64 MFMA GEMM for gfx950 with per-tile triangular k ranges, lower-only output,
+// batching and split-K.  See common.h for the argument contract.
+#include "gemm_core.h"
+
+namespace gpfit {
+
+template <bool A_KMAJOR, bool B_KMAJOR, bool EDGE>
+__global__ __launch_bounds__(GEMM_THREADS, 2) void dgemm_mfma_kernel(GemmArgs p, int tiles_n) {
+  __shared__ __attribute__((aligned(16))) double smem[4 * LDS_TILE];
+
+  int ti, tj;
+  if (p.out_lower) {
+    tri_tile(blockIdx.x, ti, tj);
+  } else {
+    ti = blockIdx.x / tiles_n;
+    tj = blockIdx.x % tiles_n;
+  }
+  const int row0 = ti * TILE, col0 = tj * TILE;
+  const int b = blockIdx.y, z = blockIdx.z;
+  const double* A = p.A + (int64_t)b * p.sA;
+  const double* B = p.B + (int64_t)b * p.sB;
+  double* C = p.C + (int64_t)b * p.sC;
+
+  int kbeg = 0, kend = p.K;
+  if (p.a_tri == 1) kend = min(kend, row0 + TILE);
+  if (p.a_tri == 2) kbeg = max(kbeg, row0);
+  if (p.b_tri == 1) kbeg = max(kbeg, col0);
+  if (p.b_tri == 2) kend = min(kend, col0 + TILE);
+  if (p.split_k > 1) {
+    // split the (16-aligned) k range into split_k nearly equal 16-aligned pieces
+    const int steps = max(0, kend - kbeg) / KTILE;
+    const int per = (steps + p.split_k - 1) / p.split_k;
+    const int s0 = min(steps, z * per), s1 = min(steps, (z + 1) * per);
+    kend = kbeg + s1 * KTILE;
+    kbeg = kbeg + s0 * KTILE;
+    C += (int64_t)z * p.sC;
+  }
+
+  v4d acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = v4d{0.0, 0.0, 0.0, 0.0};
+
+  gemm_mainloop<A_KMAJOR, B_KMAJOR, EDGE>(A, p.lda, B, p.ldb, p.M, p.N, row0, col0, kbeg, kend, smem, acc);
+
+  const double alpha = p.alpha, beta = (p.split_k > 1) ? 0.0 : p.beta;
+  const int64_t ldc = p.ldc;
+  const int M = p.M, N = p.N;
+  if (beta == 0.0) {
+    for_each_acc(acc, row0, col0, [&](int row, int col, double v) {
+      if (!EDGE || (row < M && col < N)) C[(int64_t)row * ldc + col] = alpha * v;
+    });
+  } else {
+    for_each_acc(acc, row0, col0, [&](int row, int col, double v) {
+      if (!EDGE || (row < M && col < N)) {
+        double* c = C + (int64_t)row * ldc + col;
+        *c = alpha * v + beta * (*c);
+      }
+    });
+  }
+}
+
+int launch_gemm(const GemmArgs& a, hipStream_t s) {
+  if (a.M <= 0 || a.N <= 0) return 0;
+  if (a.K % KTILE != 0 || (a.lda & 1) || (a.ldb & 1) || (a.M & 1) || (a.N & 1)) {
+    set_error("launch_gemm: K must be a multiple of 16 and M, N, lda, ldb even");
+    return -3;
+  }
+  if (a.out_lower && a.M != a.N) {
+    set_error("launch_gemm: out_lower needs a square output");
+    return -3;
+  }
+  const int tm = (a.M + TILE - 1) / TILE, tn = (a.N + TILE - 1) / TILE;
+  const int tiles = a.out_lower ? tm * (tm + 1) / 2 : tm * tn;
+  const bool edge = (a.M % TILE) || (a.N % TILE);
+  dim3 grid(tiles, a.batch > 0 ? a.batch : 1, a.split_k > 1 ? a.split_k : 1);
+  dim3 block(GEMM_THREADS);
+  GemmArgs p = a;
+  if (p.batch <= 0) p.batch = 1;
+#define GP_LAUNCH(AK, BK, ED) \
+  hipLaunchKernelGGL((dgemm_mfma_kernel<AK, BK, ED>), grid, block, 0, s, p, tn)
+  const int sel = (a.a_kmajor ? 4 : 0) | (a.b_kmajor ? 2 : 0) | (edge ? 1 : 0);
+  switch (sel) {
+    case 0: GP_LAUNCH(false, false, false); break;
+    case 1: GP_LAUNCH(false, false, true); break;
+    case 2: GP_LAUNCH(false, true, false); break;
+    case 3: GP_LAUNCH(false, true, true); break;
+    case 4: GP_LAUNCH(true, false, false); break;
+    case 5: GP_LAUNCH(true, false, true); break;
+    case 6: GP_LAUNCH(true, true, false); break;
+    case 7: GP_LAUNCH(true, true, true); break;
+  }
+#undef GP_LAUNCH
+  GP_HIP(hipGetLastError());
+  return 0;
+}
+
+}  // namespace gpfit

@@ -1,0 +1,86 @@
+/* gpfit_mi355x.h -- C ABI of the MI355X-native GP fit path (libgpfit_mi355x.so).
+ *
+ * Drop-in boundary for the hot path of Spatial_GP_repo/utils.py (the reference has no
+ * FFI layer of its own; the Python module gaussian_processes_amd/utils.py binds these
+ * entry points with ctypes and keeps the reference's function signatures).
+ *
+ * Conventions
+ *   - every matrix/vector pointer is a DEVICE pointer to contiguous row-major fp64 unless
+ *     the parameter is documented as host; the caller owns every buffer; the library
+ *     owns only the workspace inside a gpfit_ctx;
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); calls enqueue
+ *     work and return unless documented as synchronising;
+ *   - return value: 0 ok; > 0 LAPACK-style info (1-based index of the first
+ *     non-positive pivot); < 0 argument / runtime error (-2 = hyperparameter outside
+ *     its limits, -3 = bad argument, -100 = HIP runtime error), message from
+ *     gpfit_last_error();
+ *   - hyperparameter vectors are double[6] in the reference's dict order
+ *     sigma_0, eps_0x, eps_0y, -2log2beta, -log2rho2, Amp  (utils.py:824).
+ */
+#ifndef GPFIT_MI355X_H
+#define GPFIT_MI355X_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GPFIT_VERSION 100
+
+int gpfit_version(void);
+const char* gpfit_last_error(void);
+
+/* Raw fp64 MFMA GEMM:  C[M,N] = alpha * op(A)[M,K] * op(B)[K,N] + beta * C.
+ * Replaces the torch `@` / torch.matmul call sites of the path (utils.py:978-982,
+ * 1012-1017, 2047-2062, 1318-1333).  a_kmajor: 0 = A stored [M][K], 1 = A stored [K][M];
+ * b_kmajor: 1 = B stored [K][N], 0 = B stored [N][K].  out_lower: compute only the 128-tiles
+ * on/below the diagonal; a_tri/b_tri: 0 dense, 1 op() lower-, 2 op() upper-triangular.
+ * K % 16 == 0; M, N, lda, ldb even. */
+int gpfit_dgemm(void* stream, int a_kmajor, int b_kmajor, int M, int N, int K, double alpha,
+                const double* A, int64_t lda, const double* B, int64_t ldb, double beta, double* C,
+                int64_t ldc, int out_lower, int a_tri, int b_tri);
+
+/* ---- workspace context -------------------------------------------------------------
+ * One context per (device, maximum problem size); owns ~13 N^2 + O(N d) doubles of HBM
+ * workspace, one auxiliary HIP stream and two events.  A context is NOT re-entrant: calls
+ * on the same context must be serialised by the caller (one context per Python thread).
+ * n_max: stimuli; d_max: masked pixels; d_full_max: pixels of the full image. */
+typedef struct gpfit_ctx gpfit_ctx;
+int gpfit_ctx_create(int device, int64_t n_max, int64_t d_max, int64_t d_full_max, gpfit_ctx** out);
+void gpfit_ctx_destroy(gpfit_ctx* ctx);
+
+/* Hyperparameter box check of localker (utils.py:865-867) / closure_hyperparams
+ * (utils.py:2020-2028).  0 inside, -2 outside (message names the offender).  Host only. */
+int gpfit_check_limits(const double* theta, const double* lower, const double* upper);
+
+/* Pixel mask of localker (utils.py:880-883) for an n_rows x n_cols grid: mask_host[p] = 1
+ * where alpha_p >= 0.001; *d_out = number of kept pixels.  Host only (n_rows*n_cols exps). */
+int gpfit_localker_mask(const double* theta, int n_rows, int n_cols, uint8_t* mask_host, int64_t* d_out);
+
+/* The fused unit of work: ONE evaluation of the M-step closure (utils.py:2017-2112) in the
+ * full-rank regime (n_tilde == n_t, all eigenvalues kept), original basis:
+ *   localker -> acosker (K~, Kvec) -> Cholesky(K~), Cholesky(V) -> lambda moments, f,
+ *   log-likelihood, KL -> the six analytic gradients.
+ * X[N][ldx] is the UN-masked stimulus matrix (device), r, m [N], V[N][ldv] symmetric (device).
+ * out_host[16] (HOST): 0 loss = -(loglik - KL), 1 loglik, 2 KL, 3..8 d loss/d theta (dict order),
+ *   9 log|K~|, 10 log|V|, 11 tr(K~^-1 V), 12 m^T K~^-1 m, 13 masked pixel count,
+ *   14 info(K~), 15 info(V).
+ * lam_m/lam_var/f (device, [N]) may be NULL.  Synchronises `stream` before returning.
+ * Returns 0; -2 when theta is outside [lower, upper] (out_host[0] = +inf and gradients
+ * +inf, exactly what the reference closure hands to L-BFGS); > 0 LAPACK info. */
+int gpfit_fit_eval(gpfit_ctx* ctx, void* stream, const double* theta, const double* lower,
+                   const double* upper, int n_rows, int n_cols, const double* X, int64_t ldx, int64_t N,
+                   const double* r, const double* m, const double* V, int64_t ldv, double logA,
+                   double lambda0, int want_grad, double* out_host, double* lam_m, double* lam_var,
+                   double* f);
+
+/* Roofline probes (no reference counterpart): back-to-back v_mfma_f64_16x16x4_f64 issue
+ * (flops = blocks*4 waves*iters*8*2048) and a 16-byte-per-lane stream copy. */
+int gpfit_probe_mfma_f64(void* stream, double* scratch, int blocks, int iters);
+int gpfit_probe_stream_copy(void* stream, const double* in, double* out, int64_t n_doubles);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GPFIT_MI355X_H */
