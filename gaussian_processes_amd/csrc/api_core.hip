@@ -16,6 +16,10 @@ const char* gpfit_last_error(void) { return gpfit::g_err.c_str(); }
 int gpfit_dgemm(void* stream, int a_kmajor, int b_kmajor, int M, int N, int K, double alpha,
                 const double* A, int64_t lda, const double* B, int64_t ldb, double beta, double* C,
                 int64_t ldc, int out_lower, int a_tri, int b_tri) {
+  if ((M & 1) || (N & 1)) {
+    gpfit::set_error("gpfit_dgemm: M and N must be even");
+    return -3;
+  }
   gpfit::GemmArgs g{};
   g.A = A; g.B = B; g.C = C;
   g.lda = lda; g.ldb = ldb; g.ldc = ldc;

@@ -68,6 +68,7 @@ struct GramArgs {
   double* Kout;       // [..][ldk]
   double* Cos;        // same shape as Kout, or nullptr
   int64_t ld1, ld2, ldk;
+  int64_t ldcos;      // leading dimension of Cos (0: same as ldk)
   int np1, np2, nv1, nv2, Kd;
   double s0sq;
   int lower;

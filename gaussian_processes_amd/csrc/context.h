@@ -15,10 +15,11 @@ struct gpfit_ctx {
          *TmpV = nullptr;
   // N x d / d x d
   double *Xt = nullptr, *Xm = nullptr, *XCt = nullptr, *Cmat = nullptr, *Ybuf = nullptr, *Mpart = nullptr,
-         *Mmat = nullptr;
+         *Mmat = nullptr, *Xt2 = nullptr, *XCt2 = nullptr, *XDt = nullptr, *XDt2 = nullptr, *dCpad = nullptr;
   // vectors (np_cap each unless noted)
   double *Kvec = nullptr, *q = nullptr, *lam_m = nullptr, *lam_var = nullptr, *fvec = nullptr, *wl = nullptr,
-         *yv = nullptr, *bv = nullptr, *tvec = nullptr /* 2 np */, *mpad = nullptr, *rpad = nullptr;
+         *yv = nullptr, *bv = nullptr, *tvec = nullptr /* 2 np */, *mpad = nullptr, *rpad = nullptr,
+         *q2 = nullptr, *dq1 = nullptr, *dq2 = nullptr, *hvec = nullptr;
   double *upart = nullptr, *vpart = nullptr, *sumA_part = nullptr, *frob_part = nullptr, *trmv_part = nullptr;
   double* scal = nullptr;       // device scalars [64]
   double* scal_host = nullptr;  // pinned [64]
@@ -29,11 +30,28 @@ struct gpfit_ctx {
   std::vector<void*> allocs;
   int split_k_M = 32;
 
+  // optional per-launch event timing of the dominant kernels (bench.py roofline leg)
+  int profile = 0;
+  struct ProfRec { hipEvent_t a, b; double flops; int kind; };  // kind 0 gemm, 1 leaf, 2 gram
+  std::vector<ProfRec> prof;
+  std::vector<hipEvent_t> ev_pool;
+  double prof_out[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+
   // cached state of the last upload / evaluation (used by estep / predict entry points)
   int cur_n = 0, cur_np = 0, cur_d = 0, cur_dp = 0;
 };
 
 namespace gpfit {
+
+// profiling scope: when a context with profile=1 is evaluating, launches are bracketed by events
+void prof_begin(gpfit_ctx* c);
+void prof_end(gpfit_ctx* c);   // synchronises and fills c->prof_out
+struct ProfScope {
+  hipStream_t s; double flops; int kind; hipEvent_t a = nullptr;
+  ProfScope(hipStream_t s, double flops, int kind);
+  ~ProfScope();
+};
+double gemm_flops(const GemmArgs& g);
 
 struct CholBufs {
   double* A;    // input, lower triangle; destroyed

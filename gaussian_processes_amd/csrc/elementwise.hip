@@ -90,7 +90,7 @@ __global__ void gather_kernel(const double* __restrict__ X, int64_t ldx, int n, 
   for (int r = 0; r < 4; ++r) {
     const int nn = n0 + ty + 8 * r, k = k0 + tx;
     double v = 0.0;
-    if (nn < n && k < d) v = X[(int64_t)nn * ldx + pix[k]];
+    if (nn < n && k < d) v = X[(int64_t)nn * ldx + (pix ? pix[k] : k)];
     tile[ty + 8 * r][tx] = v;
     if (Xm) Xm[(int64_t)nn * ldm + k] = v;
   }
@@ -509,6 +509,116 @@ int launch_metric_contract(const Theta& th, const int* pix, int d, int n_rows, i
                            int64_t ldc, const double* M, int64_t ldm, double* grad5, hipStream_t s) {
   hipLaunchKernelGGL(metric_contract_kernel, dim3(1), dim3(1024), 0, s, th, pix, d, n_rows, n_cols, C, ldc, M,
                      ldm, grad5);
+  GP_HIP(hipGetLastError());
+  return 0;
+}
+
+// ------------------------------------------------------------------ generic API helpers
+// dst[dp][ldd] <- src[d][lds] zero padded
+__global__ void pad_copy_kernel(const double* __restrict__ src, int64_t lds, int rows, int cols,
+                                double* __restrict__ dst, int64_t ldd, int prow, int pcol) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y;
+  if (j >= pcol || i >= prow) return;
+  dst[(int64_t)i * ldd + j] = (i < rows && j < cols) ? src[(int64_t)i * lds + j] : 0.0;
+}
+
+int launch_pad_copy(const double* src, int64_t lds, int rows, int cols, double* dst, int64_t ldd, int prow,
+                    int pcol, hipStream_t s) {
+  hipLaunchKernelGGL(pad_copy_kernel, dim3((pcol + 255) / 256, prow), dim3(256), 0, s, src, lds, rows, cols, dst,
+                     ldd, prow, pcol);
+  GP_HIP(hipGetLastError());
+  return 0;
+}
+
+// K <- (K + K^T)/2 for a square n x n matrix (reference utils.py:1024-1025 when n1 == n2 but x1 != x2)
+__global__ void symmetrize_avg_kernel(double* __restrict__ A, int64_t lda, int n) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y;
+  if (i >= n || j >= i) return;
+  const double a = A[(int64_t)i * lda + j], b = A[(int64_t)j * lda + i];
+  const double v = (a + b) / 2.0;
+  A[(int64_t)i * lda + j] = v;
+  A[(int64_t)j * lda + i] = v;
+}
+
+int launch_symmetrize_avg(double* A, int64_t lda, int n, hipStream_t s) {
+  hipLaunchKernelGGL(symmetrize_avg_kernel, dim3((n + 255) / 256, n), dim3(256), 0, s, A, lda, n);
+  GP_HIP(hipGetLastError());
+  return 0;
+}
+
+// dK/dsigma_0 (utils.py:996-1004): pure element-wise from q1, q2 and cos(delta)
+__global__ void dk_sigma0_kernel(const double* __restrict__ Cos, int64_t ldc, const double* __restrict__ q1,
+                                 const double* __restrict__ q2, int n1, int n2, double s0,
+                                 double* __restrict__ dK, int64_t ldk) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y;
+  if (i >= n1 || j >= n2) return;
+  const double c = Cos[(int64_t)i * ldc + j];
+  const double a = q1[i], b = q2[j], qq = a * b;
+  const double delta = acos(c);
+  const double J = (sqrt(1.0 - c * c) + PI32 * c - delta * c) / PI32;
+  const double dqq = s0 * s0 * (b / a + a / b);        // :996
+  const double dcos = (2.0 * s0 * s0 - c * dqq) / qq;  // :998
+  const double dJ = -(delta - PI32) * dcos / PI32;     // :1000
+  dK[(int64_t)i * ldk + j] = (qq * dJ + dqq * J) / s0; // :1004
+}
+
+int launch_dk_sigma0(const double* Cos, int64_t ldc, const double* q1, const double* q2, int n1, int n2,
+                     double s0, double* dK, int64_t ldk, hipStream_t s) {
+  hipLaunchKernelGGL(dk_sigma0_kernel, dim3((n2 + 255) / 256, n1), dim3(256), 0, s, Cos, ldc, q1, q2, n1, n2, s0,
+                     dK, ldk);
+  GP_HIP(hipGetLastError());
+  return 0;
+}
+
+// dq[i] = 0.5 * sum_k Xt[k][i] * XDt[k][i] / q[i]   (utils.py:1012-1013);  h = the plain sum (:1042)
+__global__ void dq_kernel(const double* __restrict__ Xt, const double* __restrict__ XDt, int64_t ld, int dp,
+                          int n, const double* __restrict__ q, double* __restrict__ dq, double* __restrict__ h) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double v = 0.0;
+  for (int k = 0; k < dp; ++k) v += Xt[(int64_t)k * ld + i] * XDt[(int64_t)k * ld + i];
+  if (h) h[i] = v;
+  if (dq) dq[i] = 0.5 * v / q[i];
+}
+
+int launch_dq(const double* Xt, const double* XDt, int64_t ld, int dp, int n, const double* q, double* dq,
+              double* h, hipStream_t s) {
+  hipLaunchKernelGGL(dq_kernel, dim3((n + 255) / 256), dim3(256), 0, s, Xt, XDt, ld, dp, n, q, dq, h);
+  GP_HIP(hipGetLastError());
+  return 0;
+}
+
+// dK_p = qq dJ + dqq J from H = x1 dC_p x2^T (utils.py:1015-1021); H is overwritten in place
+__global__ void dk_metric_kernel(double* __restrict__ H, int64_t ldh, const double* __restrict__ Cos, int64_t ldc,
+                                 const double* __restrict__ q1, const double* __restrict__ q2,
+                                 const double* __restrict__ dq1, const double* __restrict__ dq2, int n1, int n2) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y;
+  if (i >= n1 || j >= n2) return;
+  const double c = Cos[(int64_t)i * ldc + j];
+  const double a = q1[i], b = q2[j], qq = a * b;
+  const double delta = acos(c);
+  const double J = (sqrt(1.0 - c * c) + PI32 * c - delta * c) / PI32;
+  const double dqq = dq1[i] * b + a * dq2[j];                       // :1015
+  const double dcos = (H[(int64_t)i * ldh + j] - c * dqq) / qq;      // :1017
+  const double dJ = -(delta - PI32) * dcos / PI32;                   // :1019
+  H[(int64_t)i * ldh + j] = qq * dJ + dqq * J;                       // :1021
+}
+
+int launch_dk_metric(double* H, int64_t ldh, const double* Cos, int64_t ldc, const double* q1, const double* q2,
+                     const double* dq1, const double* dq2, int n1, int n2, hipStream_t s) {
+  hipLaunchKernelGGL(dk_metric_kernel, dim3((n2 + 255) / 256, n1), dim3(256), 0, s, H, ldh, Cos, ldc, q1, q2, dq1,
+                     dq2, n1, n2);
+  GP_HIP(hipGetLastError());
+  return 0;
+}
+
+__global__ void fill_kernel(double* __restrict__ x, int64_t n, double v) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) x[i] = v;
+}
+
+int launch_fill(double* x, int64_t n, double v, hipStream_t s) {
+  hipLaunchKernelGGL(fill_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, n, v);
   GP_HIP(hipGetLastError());
   return 0;
 }

@@ -5,11 +5,83 @@
 #include "context.h"
 #include "gpfit_mi355x.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 #include <limits>
 
 namespace gpfit {
+
+// ------------------------------------------------------------------ per-launch profiling
+static thread_local gpfit_ctx* g_prof = nullptr;
+
+static hipEvent_t prof_event(gpfit_ctx* c) {
+  hipEvent_t e;
+  if (!c->ev_pool.empty()) {
+    e = c->ev_pool.back();
+    c->ev_pool.pop_back();
+    return e;
+  }
+  (void)hipEventCreate(&e);
+  return e;
+}
+
+void prof_begin(gpfit_ctx* c) {
+  if (c->profile) {
+    g_prof = c;
+    c->prof.clear();
+  }
+}
+
+void prof_end(gpfit_ctx* c) {
+  if (g_prof != c) return;
+  g_prof = nullptr;
+  (void)hipDeviceSynchronize();
+  double ms[3] = {0, 0, 0}, fl[3] = {0, 0, 0}, cnt[3] = {0, 0, 0};
+  for (auto& r : c->prof) {
+    float t = 0.f;
+    (void)hipEventElapsedTime(&t, r.a, r.b);
+    ms[r.kind] += t;
+    fl[r.kind] += r.flops;
+    cnt[r.kind] += 1;
+    c->ev_pool.push_back(r.a);
+    c->ev_pool.push_back(r.b);
+  }
+  c->prof.clear();
+  c->prof_out[0] = ms[0]; c->prof_out[1] = fl[0]; c->prof_out[2] = cnt[0];
+  c->prof_out[3] = ms[1]; c->prof_out[4] = cnt[1];
+  c->prof_out[5] = ms[2]; c->prof_out[6] = fl[2]; c->prof_out[7] = cnt[2];
+}
+
+ProfScope::ProfScope(hipStream_t s_, double flops_, int kind_) : s(s_), flops(flops_), kind(kind_) {
+  if (g_prof) {
+    a = prof_event(g_prof);
+    (void)hipEventRecord(a, s);
+  }
+}
+ProfScope::~ProfScope() {
+  if (g_prof && a) {
+    hipEvent_t b = prof_event(g_prof);
+    (void)hipEventRecord(b, s);
+    g_prof->prof.push_back({a, b, flops, kind});
+  }
+}
+
+// flops actually executed by one GEMM launch (whole 128-tiles over each tile's k range)
+double gemm_flops(const GemmArgs& g) {
+  const int tm = (g.M + TILE - 1) / TILE, tn = (g.N + TILE - 1) / TILE;
+  double steps = 0;
+  for (int ti = 0; ti < tm; ++ti)
+    for (int tj = 0; tj < (g.out_lower ? ti + 1 : tn); ++tj) {
+      int kb = 0, ke = g.K;
+      if (g.a_tri == 1) ke = std::min(ke, ti * TILE + TILE);
+      if (g.a_tri == 2) kb = std::max(kb, ti * TILE);
+      if (g.b_tri == 1) kb = std::max(kb, tj * TILE);
+      if (g.b_tri == 2) ke = std::min(ke, tj * TILE + TILE);
+      if (ke > kb) steps += (ke - kb);
+    }
+  return 2.0 * TILE * TILE * steps * (g.batch > 0 ? g.batch : 1);
+}
 
 // ------------------------------------------------------------------ GEMM convenience
 static int gemm(hipStream_t s, int a_kmajor, int b_kmajor, int M, int N, int K, double alpha, const double* A,
@@ -23,6 +95,7 @@ static int gemm(hipStream_t s, int a_kmajor, int b_kmajor, int M, int N, int K, 
   g.a_kmajor = a_kmajor; g.b_kmajor = b_kmajor;
   g.out_lower = out_lower; g.a_tri = a_tri; g.b_tri = b_tri;
   g.batch = 1; g.split_k = 1;
+  ProfScope ps(s, g_prof ? gemm_flops(g) : 0.0, 0);
   return launch_gemm(g, s);
 }
 
@@ -36,8 +109,10 @@ static int gemm(hipStream_t s, int a_kmajor, int b_kmajor, int M, int N, int K, 
 int potrf_rec(const CholBufs& B, int r0, int n, bool need_inv, hipStream_t s) {
   const int64_t ld = B.ld;
   auto at = [&](double* base, int r, int c) { return base + (int64_t)r * ld + c; };
-  if (n == TILE)
+  if (n == TILE) {
+    ProfScope ps(s, 0.0, 1);
     return launch_chol_leaf(at(B.A, r0, r0), ld, at(B.L, r0, r0), ld, at(B.Li, r0, r0), ld, B.info, r0, s);
+  }
   const int k = n / TILE;
   const int n1 = ((k + 1) / 2) * TILE, n2 = n - n1;
   const int r1 = r0 + n1;
@@ -135,6 +210,8 @@ int gpfit_ctx_create(int device, int64_t n_max, int64_t d_max, int64_t d_full_ma
   A(&c->TmpV, nn);
   A(&c->Xt, dp * np); A(&c->Xm, np * dp); A(&c->XCt, dp * np); A(&c->Cmat, dp * dp); A(&c->Ybuf, np * dp);
   A(&c->Mpart, (size_t)c->split_k_M * dp * dp); A(&c->Mmat, dp * dp);
+  A(&c->Xt2, dp * np); A(&c->XCt2, dp * np); A(&c->XDt, dp * np); A(&c->XDt2, dp * np); A(&c->dCpad, dp * dp);
+  A(&c->q2, np); A(&c->dq1, np); A(&c->dq2, np); A(&c->hvec, np);
   A(&c->Kvec, np); A(&c->q, np); A(&c->lam_m, np); A(&c->lam_var, np); A(&c->fvec, np); A(&c->wl, np);
   A(&c->yv, np); A(&c->bv, np); A(&c->tvec, 2 * np); A(&c->mpad, np); A(&c->rpad, np);
   const size_t t64 = np / 64;
@@ -176,6 +253,18 @@ void gpfit_ctx_destroy(gpfit_ctx* c) {
   if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
   if (c->ev_join) (void)hipEventDestroy(c->ev_join);
   delete c;
+}
+
+int gpfit_set_profile(gpfit_ctx* c, int on) {
+  if (!c) return -3;
+  c->profile = on ? 1 : 0;
+  return 0;
+}
+
+int gpfit_get_profile(gpfit_ctx* c, double* out8) {
+  if (!c || !out8) return -3;
+  for (int i = 0; i < 8; ++i) out8[i] = c->prof_out[i];
+  return 0;
 }
 
 int gpfit_check_limits(const double* theta, const double* lower, const double* upper) {
@@ -227,6 +316,8 @@ int gpfit_fit_eval(gpfit_ctx* c, void* stream, const double* theta, const double
   const int64_t ld = np;
   c->cur_n = n; c->cur_np = np; c->cur_d = d; c->cur_dp = dp;
 
+  prof_begin(c);
+  struct ProfGuard { gpfit_ctx* c; ~ProfGuard() { prof_end(c); } } prof_guard{c};
   GP_HIP(hipMemsetAsync(c->info, 0, 4 * sizeof(int), s));
   GP_HIP(hipMemcpyAsync(c->pix, c->pix_host, (size_t)d * sizeof(int), hipMemcpyHostToDevice, s));
   GP_HIP(hipMemsetAsync(c->mpad, 0, (size_t)np * sizeof(double), s));
@@ -252,6 +343,7 @@ int gpfit_fit_eval(gpfit_ctx* c, void* stream, const double* theta, const double
     g.XCt = c->XCt; g.Xt = c->Xt; g.q1 = c->q; g.q2 = c->q; g.Kout = c->Kbuf; g.Cos = c->Cos;
     g.ld1 = ld; g.ld2 = ld; g.ldk = ld; g.np1 = np; g.np2 = np; g.nv1 = n; g.nv2 = n; g.Kd = dp;
     g.s0sq = s0sq; g.lower = 1; g.pad_identity = 1;
+    ProfScope ps(s, (double)np * (np + TILE) * dp, 2);
     GP_TRY(launch_gram(g, s));
   }
   GP_TRY(launch_moments(c->Kvec, c->q, c->Cos, ld, V, ldv, m, r, n, A, lambda0, c->lam_m, c->lam_var, c->fvec,
@@ -291,7 +383,10 @@ int gpfit_fit_eval(gpfit_ctx* c, void* stream, const double* theta, const double
       g.M = dp; g.N = dp; g.K = np;
       g.alpha = 1.0; g.beta = 0.0; g.a_kmajor = 1; g.b_kmajor = 1;
       g.batch = 1; g.split_k = c->split_k_M; g.sC = (int64_t)dp * dp;
-      GP_TRY(launch_gemm(g, s));
+      {
+        ProfScope ps(s, g_prof ? gemm_flops(g) : 0.0, 0);
+        GP_TRY(launch_gemm(g, s));
+      }
       GP_TRY(launch_reduce_slices(c->Mpart, (int64_t)dp * dp, c->split_k_M, c->Mmat, (int64_t)dp * dp, s));
     }
     GP_TRY(launch_metric_contract(th, c->pix, d, n_rows, n_cols, c->Cmat, dp, c->Mmat, dp, c->scal + 10, s));

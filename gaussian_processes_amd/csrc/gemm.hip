@@ -63,8 +63,10 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void dgemm_mfma_kernel(GemmArgs p,
 
 int launch_gemm(const GemmArgs& a, hipStream_t s) {
   if (a.M <= 0 || a.N <= 0) return 0;
-  if (a.K % KTILE != 0 || (a.lda & 1) || (a.ldb & 1) || (a.M & 1) || (a.N & 1)) {
-    set_error("launch_gemm: K must be a multiple of 16 and M, N, lda, ldb even");
+  // odd M/N are fine for the stores; k-major operands are then read one element past M/N,
+  // which internal callers cover with zero padding (the public gpfit_dgemm insists on even).
+  if (a.K % KTILE != 0 || (a.lda & 1) || (a.ldb & 1)) {
+    set_error("launch_gemm: K must be a multiple of 16 and lda, ldb even");
     return -3;
   }
   if (a.out_lower && a.M != a.N) {

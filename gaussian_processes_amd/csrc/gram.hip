@@ -37,6 +37,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gram_acos_kernel(GramArgs p, 
   const int nv1 = p.nv1, nv2 = p.nv2;
   const bool pad_id = p.pad_identity != 0;
   const int64_t ldk = p.ldk;
+  const int64_t ldcos = p.ldcos ? p.ldcos : p.ldk;
   const double s0sq = p.s0sq;
   const double* __restrict__ q1 = p.q1;
   const double* __restrict__ q2 = p.q2;
@@ -45,11 +46,12 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gram_acos_kernel(GramArgs p, 
 
   for_each_acc(acc, row0, col0, [&](int row, int col, double g) {
     const int64_t o = (int64_t)row * ldk + col;
+    const int64_t oc = (int64_t)row * ldcos + col;
     if (row >= nv1 || col >= nv2) {
       // padding: identity on the diagonal so the padded matrix factorises as [L 0; 0 I]
       if (pad_id) {
         Ko[o] = (row == col) ? 1.0 : 0.0;
-        if (Co) Co[o] = 0.0;
+        if (Co) Co[oc] = 0.0;
       }
       return;
     }
@@ -59,7 +61,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gram_acos_kernel(GramArgs p, 
     const double delta = acos(c);
     const double J = (sqrt(1.0 - c * c) + PI32 * c - delta * c) / PI32;
     Ko[o] = qq * J;
-    if (Co) Co[o] = c;
+    if (Co) Co[oc] = c;
   });
 }
 

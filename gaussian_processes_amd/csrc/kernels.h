@@ -75,4 +75,16 @@ int launch_reduce_slices(const double* src, int64_t slice_stride, int nslice, do
 int launch_metric_contract(const Theta& th, const int* pix, int d, int n_rows, int n_cols, const double* C,
                            int64_t ldc, const double* M, int64_t ldm, double* grad5, hipStream_t s);
 
+// ---- helpers of the general (materialising) acosker / localker entry points
+int launch_pad_copy(const double* src, int64_t lds, int rows, int cols, double* dst, int64_t ldd, int prow,
+                    int pcol, hipStream_t s);
+int launch_symmetrize_avg(double* A, int64_t lda, int n, hipStream_t s);
+int launch_dk_sigma0(const double* Cos, int64_t ldc, const double* q1, const double* q2, int n1, int n2,
+                     double s0, double* dK, int64_t ldk, hipStream_t s);
+int launch_dq(const double* Xt, const double* XDt, int64_t ld, int dp, int n, const double* q, double* dq,
+              double* h, hipStream_t s);
+int launch_dk_metric(double* H, int64_t ldh, const double* Cos, int64_t ldc, const double* q1, const double* q2,
+                     const double* dq1, const double* dq2, int n1, int n2, hipStream_t s);
+int launch_fill(double* x, int64_t n, double v, hipStream_t s);
+
 }  // namespace gpfit

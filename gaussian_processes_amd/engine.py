@@ -1,0 +1,132 @@
+"""Thin Python host layer over the C ABI: one ``GPFitEngine`` = one ``gpfit_ctx`` on one GPU.
+
+torch is used for device memory and the current HIP stream only; every number is
+produced by the hand-written HIP kernels behind ``libgpfit_mi355x.so``."""
+from __future__ import annotations
+
+import ctypes
+import math
+
+import torch
+
+from . import _lib
+from .synthetic import THETA_KEYS
+
+
+def _grid(n_px_side):
+    if isinstance(n_px_side, (tuple, list)):
+        return int(n_px_side[0]), int(n_px_side[1])
+    n = int(round(float(n_px_side)))
+    return n, n
+
+
+def _scalar(v) -> float:
+    return float(v.item()) if hasattr(v, "item") else float(v)
+
+
+def theta_vec(theta):
+    if isinstance(theta, dict):
+        return [_scalar(theta[k]) for k in THETA_KEYS]
+    return [_scalar(v) for v in theta]
+
+
+class GPFitEngine:
+    """Workspace + entry points for the GP fit hot path on one MI355X."""
+
+    def __init__(self, n_max: int, d_max: int, d_full_max: int | None = None, device: int = 0):
+        if not torch.cuda.is_available():
+            raise _lib.GpfitError("GPFitEngine needs a GPU: the GP fit path has no CPU fallback")
+        self.lib = _lib.load()
+        self.device = int(device)
+        self.tdev = torch.device("cuda", self.device)
+        self.n_max, self.d_max = int(n_max), int(d_max)
+        self.d_full_max = int(d_full_max or d_max)
+        ctx = ctypes.c_void_p()
+        _lib.check(self.lib.gpfit_ctx_create(self.device, self.n_max, self.d_max, self.d_full_max,
+                                            ctypes.byref(ctx)), "gpfit_ctx_create")
+        self._ctx = ctx
+
+    def close(self):
+        if getattr(self, "_ctx", None):
+            self.lib.gpfit_ctx_destroy(self._ctx)
+            self._ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _stream(self):
+        return ctypes.c_void_p(torch.cuda.current_stream(self.tdev).cuda_stream)
+
+    def _dev(self, t, name):
+        if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float64):
+            raise TypeError(f"{name} must be a float64 CUDA tensor")
+        if t.dim() == 2 and t.stride(1) != 1:
+            t = t.contiguous()
+        if t.dim() == 1 and t.stride(0) != 1:
+            t = t.contiguous()
+        return t
+
+    def set_profile(self, on: bool):
+        _lib.check(self.lib.gpfit_set_profile(self._ctx, 1 if on else 0), "gpfit_set_profile")
+
+    def get_profile(self):
+        out = (ctypes.c_double * 8)()
+        _lib.check(self.lib.gpfit_get_profile(self._ctx, out), "gpfit_get_profile")
+        return {"gemm_ms": out[0], "gemm_flops": out[1], "gemm_launches": int(out[2]), "leaf_ms": out[3],
+                "leaf_launches": int(out[4]), "gram_ms": out[5], "gram_flops": out[6]}
+
+    def mask(self, theta, n_px_side):
+        """Pixel mask of localker (utils.py:880-883) as a host bool tensor, and its count."""
+        rows, cols = _grid(n_px_side)
+        buf = (ctypes.c_uint8 * (rows * cols))()
+        d = ctypes.c_int64()
+        _lib.check(self.lib.gpfit_localker_mask(_lib.darr(theta_vec(theta)), rows, cols, buf, ctypes.byref(d)),
+                   "gpfit_localker_mask")
+        return torch.tensor(list(buf), dtype=torch.bool), int(d.value)
+
+    def fit_eval(self, theta, lower, upper, n_px_side, X, r, m, V, logA, lambda0, want_grad=True,
+                 want_vectors=True):
+        """One evaluation of the M-step closure (utils.py:2017-2112), full-rank regime.
+
+        Returns a dict with ``loss`` (= -logmarginal), ``loglik``, ``KL``, ``grad`` (dict in the
+        reference's key order, d loss / d theta), diagnostics, and the device vectors
+        ``lam_m, lam_var, f``.  Out-of-box theta returns loss = inf and grad = inf (reference
+        behaviour); a failed Cholesky raises ``GpfitError``."""
+        rows, cols = _grid(n_px_side)
+        X, r, m, V = self._dev(X, "X"), self._dev(r, "r"), self._dev(m, "m"), self._dev(V, "V")
+        N = X.shape[0]
+        if X.shape[1] != rows * cols:
+            raise ValueError(f"X has {X.shape[1]} pixels but the grid is {rows}x{cols}")
+        out = (ctypes.c_double * 16)()
+        lam_m = lam_var = f = None
+        ptrs = [None, None, None]
+        if want_vectors:
+            lam_m = torch.empty(N, dtype=torch.float64, device=self.tdev)
+            lam_var = torch.empty_like(lam_m)
+            f = torch.empty_like(lam_m)
+            ptrs = [lam_m.data_ptr(), lam_var.data_ptr(), f.data_ptr()]
+        lo = _lib.darr(theta_vec(lower)) if lower is not None else None
+        up = _lib.darr(theta_vec(upper)) if upper is not None else None
+        rc = self.lib.gpfit_fit_eval(self._ctx, self._stream(), _lib.darr(theta_vec(theta)), lo, up, rows, cols,
+                                     X.data_ptr(), X.stride(0), N, r.data_ptr(), m.data_ptr(), V.data_ptr(),
+                                     V.stride(0), float(logA), float(lambda0), 1 if want_grad else 0, out,
+                                     ptrs[0], ptrs[1], ptrs[2])
+        if rc > 0:
+            raise _lib.GpfitError(f"gpfit_fit_eval: {_lib.last_error()} (info={rc})")
+        _lib.check(rc, "gpfit_fit_eval")
+        res = {
+            "loss": out[0], "loglik": out[1], "KL": out[2],
+            "grad": {k: out[3 + i] for i, k in enumerate(THETA_KEYS)},
+            "logdet_K": out[9], "logdet_V": out[10], "tr_KinvV": out[11], "mKinvm": out[12],
+            "d": int(out[13]) if rc == 0 else 0, "in_bounds": rc == 0,
+            "lam_m": lam_m, "lam_var": lam_var, "f": f,
+        }
+        return res
+
+
+def fits_flops(N: int, d: int) -> float:
+    """Algorithmic flops of one unit of work, SURVEY.md 8(d): (14/3)N^3 + 4N^2 d + 4 N d^2."""
+    return (14.0 / 3.0) * N ** 3 + 4.0 * N * N * d + 4.0 * N * d * d

@@ -58,6 +58,29 @@ int gpfit_check_limits(const double* theta, const double* lower, const double* u
  * where alpha_p >= 0.001; *d_out = number of kept pixels.  Host only (n_rows*n_cols exps). */
 int gpfit_localker_mask(const double* theta, int n_rows, int n_cols, uint8_t* mask_host, int64_t* d_out);
 
+/* localker (utils.py:861-914): spatial metric C[d][d] over the kept pixels of an n_rows x
+ * n_cols grid and, when dC is non-NULL, its five derivatives as dC[5][d][d] in the order
+ * Amp, -2log2beta, -log2rho2, eps_0x, eps_0y (the key order of the reference's dC dict,
+ * utils.py:910).  mask_host/d come from gpfit_localker_mask.  Synchronises `stream`. */
+int gpfit_localker(gpfit_ctx* ctx, void* stream, const double* theta, int n_rows, int n_cols,
+                   const uint8_t* mask_host, int64_t d, double* C, double* dC);
+
+/* acosker, diag=False (utils.py:968-1025): K[n1][n2] from already-masked x1[n1][d],
+ * x2[n2][d] and the metric C[d][d]; symmetrised when n1 == n2 (utils.py:1024).  When dK is
+ * non-NULL it receives six [n1][n2] matrices in theta dict order (sigma_0, eps_0x, eps_0y,
+ * -2log2beta, -log2rho2, Amp); dC (layout as gpfit_localker) may be NULL, in which case only
+ * the sigma_0 derivative is written.  Pass x2 == x1 for the square self-kernel (lower-tile
+ * fast path).  Enqueues on `stream`, does not synchronise. */
+int gpfit_acosker(gpfit_ctx* ctx, void* stream, double sigma0, const double* x1, int64_t ld1, int64_t n1,
+                  const double* x2, int64_t ld2, int64_t n2, int64_t d, const double* C, int64_t ldC,
+                  const double* dC, double* K, int64_t ldk, double* dK);
+
+/* acosker, diag=True (utils.py:1027-1044): Kvec[n1] = x_i C x_i + sigma_0^2 and optionally
+ * dKvec[6][n1] (theta dict order). */
+int gpfit_acosker_diag(gpfit_ctx* ctx, void* stream, double sigma0, const double* x1, int64_t ld1,
+                       int64_t n1, int64_t d, const double* C, int64_t ldC, const double* dC, double* Kvec,
+                       double* dKvec);
+
 /* The fused unit of work: ONE evaluation of the M-step closure (utils.py:2017-2112) in the
  * full-rank regime (n_tilde == n_t, all eigenvalues kept), original basis:
  *   localker -> acosker (K~, Kvec) -> Cholesky(K~), Cholesky(V) -> lambda moments, f,
@@ -74,6 +97,13 @@ int gpfit_fit_eval(gpfit_ctx* ctx, void* stream, const double* theta, const doub
                    const double* r, const double* m, const double* V, int64_t ldv, double logA,
                    double lambda0, int want_grad, double* out_host, double* lam_m, double* lam_var,
                    double* f);
+
+/* Per-launch HIP-event timing of the dominant kernels during gpfit_fit_eval (bench.py's
+ * roofline leg; adds two event records per launch, so leave it off when timing throughput).
+ * out8: 0 sum of dgemm launch durations [ms], 1 flops those launches executed, 2 #launches,
+ *       3 sum of Cholesky-leaf durations [ms], 4 #leaves, 5 Gram kernel [ms], 6 its flops, 7 #. */
+int gpfit_set_profile(gpfit_ctx* ctx, int on);
+int gpfit_get_profile(gpfit_ctx* ctx, double* out8);
 
 /* Roofline probes (no reference counterpart): back-to-back v_mfma_f64_16x16x4_f64 issue
  * (flops = blocks*4 waves*iters*8*2048) and a 16-byte-per-lane stream copy. */

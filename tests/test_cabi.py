@@ -1,0 +1,69 @@
+"""CPU-side checks of the drop-in boundary: the shared library builds for gfx950, loads, and
+exports every symbol include/gpfit_mi355x.h declares; host-only entry points behave like the
+reference.  No compute call touches a GPU here."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, load_golden
+from gaussian_processes_amd import _lib, synthetic as syn
+from gaussian_processes_amd.build import build_library
+
+KEYS = syn.THETA_KEYS
+
+
+@pytest.fixture(scope="module")
+def lib():
+    build_library(verbose=False)
+    return _lib.load()
+
+
+def test_header_symbols_are_exported(lib):
+    hdr = open(os.path.join(ROOT, "include", "gpfit_mi355x.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = sorted(set(re.findall(r"\b(gpfit_\w+)\s*\(", hdr)))
+    assert len(declared) >= 8
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in the header but not exported"
+    assert set(declared) == set(_lib.exported_symbols()), "ctypes table and header disagree"
+    assert lib.gpfit_version() == 100
+
+
+def test_check_limits_matches_reference_rule(lib):
+    lo, up = syn.limits()
+    th = syn.theta_eval()
+    v = lambda d_: _lib.darr([d_[k] for k in KEYS])
+    assert lib.gpfit_check_limits(v(th), v(lo), v(up)) == 0
+    th["eps_0y"] = -1.0  # boundary is inside (utils.py:866 uses <=)
+    assert lib.gpfit_check_limits(v(th), v(lo), v(up)) == 0
+    th["eps_0y"] = -1.0000001
+    assert lib.gpfit_check_limits(v(th), v(lo), v(up)) == -2
+    assert b"eps_0y" in lib.gpfit_last_error()
+    th = syn.theta_eval()
+    th["Amp"] = float("nan")
+    assert lib.gpfit_check_limits(v(th), v(lo), v(up)) == -2
+
+
+def test_localker_mask_matches_golden(lib):
+    g = load_golden("g1_localker.npz")
+    for i in range(int(g["n_cases"])):
+        n_px = int(g[f"c{i}_n_px"])
+        buf = (ctypes.c_uint8 * (n_px * n_px))()
+        d = ctypes.c_int64()
+        rc = lib.gpfit_localker_mask(_lib.darr(g[f"c{i}_theta"]), n_px, n_px, buf, ctypes.byref(d))
+        assert rc == 0
+        mask = np.array(list(buf), dtype=bool)
+        assert np.array_equal(mask, g[f"c{i}_mask"])
+        assert int(d.value) == int(g[f"c{i}_mask"].sum())
+
+
+def test_missing_gpu_fails_loudly():
+    import torch
+    from gaussian_processes_amd.engine import GPFitEngine
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(_lib.GpfitError):
+        GPFitEngine(64, 16)
