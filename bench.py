@@ -33,6 +33,27 @@ from gaussian_processes_amd.engine import GPFitEngine, fits_flops  # noqa: E402
 FP64_MFMA_PEAK_TFLOPS = 78.6  # MI355X dense fp64 matrix peak (AMD datasheet; rocBLAS dgemm reaches 76.7 on-box)
 
 
+def log(msg):
+    print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
+def host_cores() -> int:
+    """CPU cores this process may actually use: the cgroup quota / affinity mask, not the
+    host's core count (a 1-GPU box gives its jobs a 16-core share)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(p))))
+    except Exception:
+        pass
+    return max(1, min(n, 32))
+
+
 def build_V(X, grid, th0, dev):
     """V = K~(theta0)/2 (SPD by construction).  Setup only, outside the timed
     region; uses the library's own kernel-build entry point."""
@@ -50,8 +71,9 @@ def cpu_baseline(n_sample: int, d: int, budget_s: float = 40.0):
     eigen-projection, LU inverse, 13+13 GEMM gradient products; torch CPU fp64) timed on the
     host cores of this box on a bounded sample, plus the CPU Cholesky restatement."""
     from oracle import gp_oracle as orc
-    cores = os.cpu_count() or 1
+    cores = host_cores()
     torch.set_num_threads(cores)
+    log(f"cpu_baseline: {cores} threads, sample N={n_sample}")
     lower, upper = syn.limits()
     grid = syn.grid_for(d)
     X = torch.from_numpy(syn.stimuli(n_sample, d))
@@ -68,6 +90,7 @@ def cpu_baseline(n_sample: int, d: int, budget_s: float = 40.0):
     t0 = time.time()
     loss_ref, _ = orc.mstep_closure_reference(th1, lower, upper, grid, X, X, r, B, m_b, V_b, logA, lam0, tol=1e-14)
     t_first = time.time() - t0
+    log(f"cpu_baseline: first reference-formulation eval {t_first:.2f}s")
     reps, times = 0, [t_first]
     while sum(times) + t_first < budget_s and reps < 2:
         t0 = time.time()
@@ -124,7 +147,12 @@ def main():
     r, m = torch.from_numpy(r_np).to(dev), torch.from_numpy(m_np).to(dev)
     th0, th1 = syn.theta0(cell), syn.theta_eval(cell)
     eng = GPFitEngine(N, d, device=local_rank)
+    if rank == 0:
+        log("context ready; building V")
     V = build_V(X, grid, th0, dev)
+    torch.cuda.synchronize(dev)
+    if rank == 0:
+        log("inputs resident; warm-up")
     logA, lam0 = syn.F_PARAMS["logA"], syn.F_PARAMS["lambda0"]
     want_grad = not args.no_grad
 
@@ -151,6 +179,7 @@ def main():
     assert math.isfinite(res["loss"]), "benchmark evaluation produced a non-finite loss"
 
     if rank == 0:
+        log(f"timed region done: {elapsed / args.steps * 1e3:.2f} ms/step (host enqueue {eng.last_enqueue_ms():.2f} ms)")
         fits_per_s = world * args.steps / elapsed
         F = fits_flops(N, d)
         # ---- roofline of the dominant kernel (fp64 MFMA GEMM family), HIP events per launch

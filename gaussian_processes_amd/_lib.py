@@ -27,6 +27,7 @@ _SIGS = {
                              vp, vp, vp]),
     "gpfit_set_profile": (i32, [vp, i32]),
     "gpfit_get_profile": (i32, [vp, pd]),
+    "gpfit_last_enqueue_ms": (f64, [vp]),
     "gpfit_probe_mfma_f64": (i32, [vp, vp, i32, i32]),
     "gpfit_probe_stream_copy": (i32, [vp, vp, vp, i64]),
 }

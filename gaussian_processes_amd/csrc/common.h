@@ -35,6 +35,7 @@ inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
 //   b_kmajor = 0 : B stored [N][K] (k contiguous)   element (k,n) at B[n*ldb + k]
 // Triangular structure is exploited per 128-tile:
 //   out_lower   : only tiles with tj <= ti are computed / written (M == N)
+//   (tri k ranges are taken per block tile of the size the launcher picks)
 //   a_tri/b_tri : 0 dense, 1 op() is lower triangular, 2 op() is upper triangular
 //                 (restricts each tile's k range; the skipped part must hold zeros or is
 //                  simply never read)
@@ -52,8 +53,11 @@ struct GemmArgs {
   int batch;                 // number of independent problems (grid.y)
   int64_t sA, sB, sC;        // batch strides (elements)
   int split_k;               // >1: partial products written to C + z*sC (beta ignored)
+  int tile;                  // 0 = choose (128 / 64 / 32), else forced block tile
+  int reverse;               // walk the tile grid backwards (heaviest-last problems)
 };
 int launch_gemm(const GemmArgs& a, hipStream_t s);
+int gemm_pick_tile(const GemmArgs& a);  // block tile the launcher will use (128 / 64 / 32)
 
 // Arc-cosine Gram matrix from the k-major, zero-padded operands XCt[Kd][ld1], Xt[Kd][ld2]:
 //   G = XCt^T Xt + s0^2 ; c = clip(G/(q1 q2 + 1e-7)) ; K = q1 q2 J(c)

@@ -36,6 +36,7 @@ struct gpfit_ctx {
   std::vector<ProfRec> prof;
   std::vector<hipEvent_t> ev_pool;
   double prof_out[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  double last_enqueue_ms = 0.0;  // host time spent enqueuing the last fit_eval
 
   // cached state of the last upload / evaluation (used by estep / predict entry points)
   int cur_n = 0, cur_np = 0, cur_d = 0, cur_dp = 0;

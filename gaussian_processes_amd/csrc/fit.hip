@@ -6,6 +6,7 @@
 #include "gpfit_mi355x.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstring>
 #include <limits>
@@ -69,24 +70,26 @@ ProfScope::~ProfScope() {
 
 // flops actually executed by one GEMM launch (whole 128-tiles over each tile's k range)
 double gemm_flops(const GemmArgs& g) {
-  const int tm = (g.M + TILE - 1) / TILE, tn = (g.N + TILE - 1) / TILE;
+  const int T = gemm_pick_tile(g);
+  const int tm = (g.M + T - 1) / T, tn = (g.N + T - 1) / T, r = TILE / T;
   double steps = 0;
   for (int ti = 0; ti < tm; ++ti)
-    for (int tj = 0; tj < (g.out_lower ? ti + 1 : tn); ++tj) {
+    for (int tj = 0; tj < tn; ++tj) {
+      if (g.out_lower && tj / r > ti / r) continue;
       int kb = 0, ke = g.K;
-      if (g.a_tri == 1) ke = std::min(ke, ti * TILE + TILE);
-      if (g.a_tri == 2) kb = std::max(kb, ti * TILE);
-      if (g.b_tri == 1) kb = std::max(kb, tj * TILE);
-      if (g.b_tri == 2) ke = std::min(ke, tj * TILE + TILE);
+      if (g.a_tri == 1) ke = std::min(ke, ti * T + T);
+      if (g.a_tri == 2) kb = std::max(kb, ti * T);
+      if (g.b_tri == 1) kb = std::max(kb, tj * T);
+      if (g.b_tri == 2) ke = std::min(ke, tj * T + T);
       if (ke > kb) steps += (ke - kb);
     }
-  return 2.0 * TILE * TILE * steps * (g.batch > 0 ? g.batch : 1);
+  return 2.0 * T * T * steps * (g.batch > 0 ? g.batch : 1);
 }
 
 // ------------------------------------------------------------------ GEMM convenience
 static int gemm(hipStream_t s, int a_kmajor, int b_kmajor, int M, int N, int K, double alpha, const double* A,
                 int64_t lda, const double* B, int64_t ldb, double beta, double* C, int64_t ldc, int out_lower,
-                int a_tri, int b_tri) {
+                int a_tri, int b_tri, int reverse = 0) {
   GemmArgs g{};
   g.A = A; g.B = B; g.C = C;
   g.lda = lda; g.ldb = ldb; g.ldc = ldc;
@@ -94,7 +97,7 @@ static int gemm(hipStream_t s, int a_kmajor, int b_kmajor, int M, int N, int K, 
   g.alpha = alpha; g.beta = beta;
   g.a_kmajor = a_kmajor; g.b_kmajor = b_kmajor;
   g.out_lower = out_lower; g.a_tri = a_tri; g.b_tri = b_tri;
-  g.batch = 1; g.split_k = 1;
+  g.batch = 1; g.split_k = 1; g.reverse = reverse;
   ProfScope ps(s, g_prof ? gemm_flops(g) : 0.0, 0);
   return launch_gemm(g, s);
 }
@@ -261,6 +264,8 @@ int gpfit_set_profile(gpfit_ctx* c, int on) {
   return 0;
 }
 
+double gpfit_last_enqueue_ms(gpfit_ctx* c) { return c ? c->last_enqueue_ms : -1.0; }
+
 int gpfit_get_profile(gpfit_ctx* c, double* out8) {
   if (!c || !out8) return -3;
   for (int i = 0; i < 8; ++i) out8[i] = c->prof_out[i];
@@ -316,6 +321,7 @@ int gpfit_fit_eval(gpfit_ctx* c, void* stream, const double* theta, const double
   const int64_t ld = np;
   c->cur_n = n; c->cur_np = np; c->cur_d = d; c->cur_dp = dp;
 
+  const auto t_host0 = std::chrono::steady_clock::now();
   prof_begin(c);
   struct ProfGuard { gpfit_ctx* c; ~ProfGuard() { prof_end(c); } } prof_guard{c};
   GP_HIP(hipMemsetAsync(c->info, 0, 4 * sizeof(int), s));
@@ -361,7 +367,7 @@ int gpfit_fit_eval(gpfit_ctx* c, void* stream, const double* theta, const double
   GP_HIP(hipStreamWaitEvent(s, c->ev_join, 0));
   GP_TRY(launch_logdet(c->LVbuf, ld, n, c->scal + 4, s));
   // T = L^-1 L_V (lower x lower -> lower);  tr(K~^-1 V) = ||T||_F^2
-  GP_TRY(gemm(s, 0, 1, np, np, np, 1.0, c->Libuf, ld, c->LVbuf, ld, 0.0, c->Tbuf, ld, 1, 1, 1));
+  GP_TRY(gemm(s, 0, 1, np, np, np, 1.0, c->Libuf, ld, c->LVbuf, ld, 0.0, c->Tbuf, ld, 1, 1, 1, /*reverse=*/1));
   GP_TRY(launch_frob_lower(c->Tbuf, ld, np, c->scal + 5, c->frob_part, s));
 
   if (want_grad) {
@@ -397,6 +403,7 @@ int gpfit_fit_eval(gpfit_ctx* c, void* stream, const double* theta, const double
   if (f_out) GP_HIP(hipMemcpyAsync(f_out, c->fvec, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, s));
   GP_HIP(hipMemcpyAsync(c->scal_host, c->scal, 64 * sizeof(double), hipMemcpyDeviceToHost, s));
   GP_HIP(hipMemcpyAsync(c->info_host, c->info, 4 * sizeof(int), hipMemcpyDeviceToHost, s));
+  c->last_enqueue_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_host0).count();
   GP_HIP(hipStreamSynchronize(s));
 
   const double* sc = c->scal_host;

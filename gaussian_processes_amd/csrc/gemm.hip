@@ -4,28 +4,32 @@
 
 namespace gpfit {
 
-template <bool A_KMAJOR, bool B_KMAJOR, bool EDGE>
-__global__ __launch_bounds__(GEMM_THREADS, 2) void dgemm_mfma_kernel(GemmArgs p, int tiles_n) {
-  __shared__ __attribute__((aligned(16))) double smem[4 * LDS_TILE];
+template <bool A_KMAJOR, bool B_KMAJOR, bool EDGE, int T>
+__global__ __launch_bounds__(GEMM_THREADS, (T == 128 ? 2 : 4)) void dgemm_mfma_kernel(GemmArgs p, int tiles_n,
+                                                                                      int ntiles) {
+  __shared__ __attribute__((aligned(16))) double smem[4 * KTILE * T];
 
+  // heaviest tiles first: with triangular operands the k range grows with the tile index,
+  // so the grid is walked backwards when `reverse` is set (shorter tail).
+  const int bid = p.reverse ? (ntiles - 1 - (int)blockIdx.x) : (int)blockIdx.x;
   int ti, tj;
   if (p.out_lower) {
-    tri_tile(blockIdx.x, ti, tj);
+    lower_tile(bid, TILE / T, ti, tj);
   } else {
-    ti = blockIdx.x / tiles_n;
-    tj = blockIdx.x % tiles_n;
+    ti = bid / tiles_n;
+    tj = bid % tiles_n;
   }
-  const int row0 = ti * TILE, col0 = tj * TILE;
+  const int row0 = ti * T, col0 = tj * T;
   const int b = blockIdx.y, z = blockIdx.z;
   const double* A = p.A + (int64_t)b * p.sA;
   const double* B = p.B + (int64_t)b * p.sB;
   double* C = p.C + (int64_t)b * p.sC;
 
   int kbeg = 0, kend = p.K;
-  if (p.a_tri == 1) kend = min(kend, row0 + TILE);
+  if (p.a_tri == 1) kend = min(kend, row0 + T);
   if (p.a_tri == 2) kbeg = max(kbeg, row0);
   if (p.b_tri == 1) kbeg = max(kbeg, col0);
-  if (p.b_tri == 2) kend = min(kend, col0 + TILE);
+  if (p.b_tri == 2) kend = min(kend, col0 + T);
   if (p.split_k > 1) {
     // split the (16-aligned) k range into split_k nearly equal 16-aligned pieces
     const int steps = max(0, kend - kbeg) / KTILE;
@@ -36,29 +40,67 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void dgemm_mfma_kernel(GemmArgs p,
     C += (int64_t)z * p.sC;
   }
 
-  v4d acc[4][4];
+  v4d acc[T / 32][T / 32];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < T / 32; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = v4d{0.0, 0.0, 0.0, 0.0};
+    for (int j = 0; j < T / 32; ++j) acc[i][j] = v4d{0.0, 0.0, 0.0, 0.0};
 
-  gemm_mainloop<A_KMAJOR, B_KMAJOR, EDGE>(A, p.lda, B, p.ldb, p.M, p.N, row0, col0, kbeg, kend, smem, acc);
+  gemm_mainloop<A_KMAJOR, B_KMAJOR, EDGE, T>(A, p.lda, B, p.ldb, p.M, p.N, row0, col0, kbeg, kend, smem, acc);
 
   const double alpha = p.alpha, beta = (p.split_k > 1) ? 0.0 : p.beta;
   const int64_t ldc = p.ldc;
   const int M = p.M, N = p.N;
   if (beta == 0.0) {
-    for_each_acc(acc, row0, col0, [&](int row, int col, double v) {
+    for_each_acc<T>(acc, row0, col0, [&](int row, int col, double v) {
       if (!EDGE || (row < M && col < N)) C[(int64_t)row * ldc + col] = alpha * v;
     });
   } else {
-    for_each_acc(acc, row0, col0, [&](int row, int col, double v) {
+    for_each_acc<T>(acc, row0, col0, [&](int row, int col, double v) {
       if (!EDGE || (row < M && col < N)) {
         double* c = C + (int64_t)row * ldc + col;
         *c = alpha * v + beta * (*c);
       }
     });
   }
+}
+
+// Tile size: 128 when that already gives the chip >= 1.5 waves of blocks, otherwise 64 / 32 so
+// the small panels near the leaves of the recursion are not serialised on a handful of CUs.
+int gemm_pick_tile(const GemmArgs& a) {
+  if (a.tile == 128 || a.tile == 64 || a.tile == 32) return a.tile;
+  auto ntiles = [&](int T) {
+    const long tm = (a.M + T - 1) / T, tn = (a.N + T - 1) / T;
+    const long nb = (a.M + TILE - 1) / TILE;
+    return (a.out_lower ? (long)lower_tile_count((int)nb, TILE / T) : tm * tn) * (a.batch > 0 ? a.batch : 1) *
+           (a.split_k > 1 ? a.split_k : 1);
+  };
+  if (ntiles(128) >= 384) return 128;
+  if (ntiles(64) >= 256) return 64;
+  return (a.M <= 1024 && a.N <= 1024) ? 32 : 64;
+}
+
+template <int T>
+static void launch_T(const GemmArgs& p, hipStream_t s) {
+  const int tm = (p.M + T - 1) / T, tn = (p.N + T - 1) / T;
+  const int tiles = p.out_lower ? lower_tile_count((p.M + TILE - 1) / TILE, TILE / T) : tm * tn;
+  const bool edge = (p.M % T) || (p.N % T) || (p.out_lower && (p.M % TILE));
+  dim3 grid(tiles, p.batch, p.split_k > 1 ? p.split_k : 1);
+  dim3 block(GEMM_THREADS);
+#define GP_LAUNCH(AK, BK, ED) \
+  hipLaunchKernelGGL((dgemm_mfma_kernel<AK, BK, ED, T>), grid, block, 0, s, p, tn, tiles)
+  const int sel = (p.a_kmajor ? 4 : 0) | (p.b_kmajor ? 2 : 0) | (edge ? 1 : 0);
+  switch (sel) {
+    case 0: GP_LAUNCH(false, false, false); break;
+    case 1: GP_LAUNCH(false, false, true); break;
+    case 2: GP_LAUNCH(false, true, false); break;
+    case 3: GP_LAUNCH(false, true, true); break;
+    case 4: GP_LAUNCH(true, false, false); break;
+    case 5: GP_LAUNCH(true, false, true); break;
+    case 6: GP_LAUNCH(true, true, false); break;
+    case 7: GP_LAUNCH(true, true, true); break;
+  }
+#undef GP_LAUNCH
 }
 
 int launch_gemm(const GemmArgs& a, hipStream_t s) {
@@ -73,27 +115,13 @@ int launch_gemm(const GemmArgs& a, hipStream_t s) {
     set_error("launch_gemm: out_lower needs a square output");
     return -3;
   }
-  const int tm = (a.M + TILE - 1) / TILE, tn = (a.N + TILE - 1) / TILE;
-  const int tiles = a.out_lower ? tm * (tm + 1) / 2 : tm * tn;
-  const bool edge = (a.M % TILE) || (a.N % TILE);
-  dim3 grid(tiles, a.batch > 0 ? a.batch : 1, a.split_k > 1 ? a.split_k : 1);
-  dim3 block(GEMM_THREADS);
   GemmArgs p = a;
   if (p.batch <= 0) p.batch = 1;
-#define GP_LAUNCH(AK, BK, ED) \
-  hipLaunchKernelGGL((dgemm_mfma_kernel<AK, BK, ED>), grid, block, 0, s, p, tn)
-  const int sel = (a.a_kmajor ? 4 : 0) | (a.b_kmajor ? 2 : 0) | (edge ? 1 : 0);
-  switch (sel) {
-    case 0: GP_LAUNCH(false, false, false); break;
-    case 1: GP_LAUNCH(false, false, true); break;
-    case 2: GP_LAUNCH(false, true, false); break;
-    case 3: GP_LAUNCH(false, true, true); break;
-    case 4: GP_LAUNCH(true, false, false); break;
-    case 5: GP_LAUNCH(true, false, true); break;
-    case 6: GP_LAUNCH(true, true, false); break;
-    case 7: GP_LAUNCH(true, true, true); break;
+  switch (gemm_pick_tile(p)) {
+    case 128: launch_T<128>(p, s); break;
+    case 64: launch_T<64>(p, s); break;
+    default: launch_T<32>(p, s); break;
   }
-#undef GP_LAUNCH
   GP_HIP(hipGetLastError());
   return 0;
 }

@@ -16,7 +16,7 @@
 namespace gpfit {
 
 __global__ __launch_bounds__(GEMM_THREADS, 2) void gram_acos_kernel(GramArgs p, int tiles_n) {
-  __shared__ __attribute__((aligned(16))) double smem[4 * LDS_TILE];
+  __shared__ __attribute__((aligned(16))) double smem[4 * KTILE * TILE];
   int ti, tj;
   if (p.lower) {
     tri_tile(blockIdx.x, ti, tj);
@@ -32,7 +32,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gram_acos_kernel(GramArgs p, 
     for (int j = 0; j < 4; ++j) acc[i][j] = v4d{0.0, 0.0, 0.0, 0.0};
 
   // operands are zero-padded to whole tiles: no edge predication on the loads
-  gemm_mainloop<true, true, false>(p.XCt, p.ld1, p.Xt, p.ld2, p.np1, p.np2, row0, col0, 0, p.Kd, smem, acc);
+  gemm_mainloop<true, true, false, TILE>(p.XCt, p.ld1, p.Xt, p.ld2, p.np1, p.np2, row0, col0, 0, p.Kd, smem, acc);
 
   const int nv1 = p.nv1, nv2 = p.nv2;
   const bool pad_id = p.pad_identity != 0;
@@ -44,7 +44,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gram_acos_kernel(GramArgs p, 
   double* __restrict__ Ko = p.Kout;
   double* __restrict__ Co = p.Cos;
 
-  for_each_acc(acc, row0, col0, [&](int row, int col, double g) {
+  for_each_acc<TILE>(acc, row0, col0, [&](int row, int col, double g) {
     const int64_t o = (int64_t)row * ldk + col;
     const int64_t oc = (int64_t)row * ldcos + col;
     if (row >= nv1 || col >= nv2) {

@@ -78,6 +78,9 @@ class GPFitEngine:
         return {"gemm_ms": out[0], "gemm_flops": out[1], "gemm_launches": int(out[2]), "leaf_ms": out[3],
                 "leaf_launches": int(out[4]), "gram_ms": out[5], "gram_flops": out[6]}
 
+    def last_enqueue_ms(self) -> float:
+        return float(self.lib.gpfit_last_enqueue_ms(self._ctx))
+
     def mask(self, theta, n_px_side):
         """Pixel mask of localker (utils.py:880-883) as a host bool tensor, and its count."""
         rows, cols = _grid(n_px_side)

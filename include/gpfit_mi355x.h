@@ -104,6 +104,8 @@ int gpfit_fit_eval(gpfit_ctx* ctx, void* stream, const double* theta, const doub
  *       3 sum of Cholesky-leaf durations [ms], 4 #leaves, 5 Gram kernel [ms], 6 its flops, 7 #. */
 int gpfit_set_profile(gpfit_ctx* ctx, int on);
 int gpfit_get_profile(gpfit_ctx* ctx, double* out8);
+/* Host milliseconds the last gpfit_fit_eval spent enqueuing work (before its final sync). */
+double gpfit_last_enqueue_ms(gpfit_ctx* ctx);
 
 /* Roofline probes (no reference counterpart): back-to-back v_mfma_f64_16x16x4_f64 issue
  * (flops = blocks*4 waves*iters*8*2048) and a 16-byte-per-lane stream copy. */

@@ -56,7 +56,7 @@ check(384, 384, 384, 0, 0, lower=1, bt=2)
 print("correctness OK")
 
 # throughput
-for (M, N, K, ak, bk) in [(8192, 8192, 8192, 0, 0), (8192, 8192, 8192, 1, 1), (8192, 8192, 8192, 0, 1), (8192, 8192, 256, 1, 1), (4096, 4096, 4096, 0, 0)]:
+for (M, N, K, ak, bk) in [(8192, 8192, 8192, 0, 0), (2048, 2048, 2048, 0, 0), (1024, 1024, 1024, 0, 0), (512, 512, 512, 0, 0), (256, 256, 256, 0, 1), (128, 128, 128, 0, 0)]:
     A = torch.randn(M if not ak else K, K if not ak else M, dtype=torch.float64, device=dev)
     B = torch.randn(K if bk else N, N if bk else K, dtype=torch.float64, device=dev)
     C = torch.empty(M, N, dtype=torch.float64, device=dev)
