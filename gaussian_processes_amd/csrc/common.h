@@ -54,7 +54,7 @@ struct GemmArgs {
   int64_t sA, sB, sC;        // batch strides (elements)
   int split_k;               // >1: partial products written to C + z*sC (beta ignored)
   int tile;                  // 0 = choose (128 / 64 / 32), else forced block tile
-  int reverse;               // walk the tile grid backwards (heaviest-last problems)
+  int reverse;               // tile walk: bit 0 backwards, bit 1 column-major (dense output)
 };
 int launch_gemm(const GemmArgs& a, hipStream_t s);
 int gemm_pick_tile(const GemmArgs& a);  // block tile the launcher will use (128 / 64 / 32)

@@ -612,6 +612,17 @@ int launch_dk_metric(double* H, int64_t ldh, const double* Cos, int64_t ldc, con
   return 0;
 }
 
+__global__ void add_diag_kernel(double* __restrict__ A, int64_t lda, int n, double v) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) A[(int64_t)i * lda + i] += v;
+}
+
+int launch_add_diag(double* A, int64_t lda, int n, double v, hipStream_t s) {
+  hipLaunchKernelGGL(add_diag_kernel, dim3((n + 255) / 256), dim3(256), 0, s, A, lda, n, v);
+  GP_HIP(hipGetLastError());
+  return 0;
+}
+
 __global__ void fill_kernel(double* __restrict__ x, int64_t n, double v) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) x[i] = v;

@@ -8,6 +8,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 
@@ -121,14 +122,14 @@ int potrf_rec(const CholBufs& B, int r0, int n, bool need_inv, hipStream_t s) {
   const int r1 = r0 + n1;
   GP_TRY(potrf_rec(B, r0, n1, true, s));
   // L21 = A21 * L11^-T       (trsm as a GEMM against the explicit inverse; op(B) = Li11^T is upper)
-  GP_TRY(gemm(s, 0, 0, n2, n1, n1, 1.0, at(B.A, r1, r0), ld, at(B.Li, r0, r0), ld, 0.0, at(B.L, r1, r0), ld, 0, 0, 2));
+  GP_TRY(gemm(s, 0, 0, n2, n1, n1, 1.0, at(B.A, r1, r0), ld, at(B.Li, r0, r0), ld, 0.0, at(B.L, r1, r0), ld, 0, 0, 2, /*walk=*/3));
   // A22 -= L21 L21^T          (syrk, lower tiles only)
   GP_TRY(gemm(s, 0, 0, n2, n2, n1, -1.0, at(B.L, r1, r0), ld, at(B.L, r1, r0), ld, 1.0, at(B.A, r1, r1), ld, 1, 0, 0));
   GP_TRY(potrf_rec(B, r1, n2, need_inv, s));
   if (need_inv) {
     // Li21 = -Li22 * (L21 * Li11)
-    GP_TRY(gemm(s, 0, 1, n2, n1, n1, 1.0, at(B.L, r1, r0), ld, at(B.Li, r0, r0), ld, 0.0, at(B.Tmp, r1, r0), ld, 0, 0, 1));
-    GP_TRY(gemm(s, 0, 1, n2, n1, n2, -1.0, at(B.Li, r1, r1), ld, at(B.Tmp, r1, r0), ld, 0.0, at(B.Li, r1, r0), ld, 0, 1, 0));
+    GP_TRY(gemm(s, 0, 1, n2, n1, n1, 1.0, at(B.L, r1, r0), ld, at(B.Li, r0, r0), ld, 0.0, at(B.Tmp, r1, r0), ld, 0, 0, 1, /*walk=*/2));
+    GP_TRY(gemm(s, 0, 1, n2, n1, n2, -1.0, at(B.Li, r1, r1), ld, at(B.Tmp, r1, r0), ld, 0.0, at(B.Li, r1, r0), ld, 0, 1, 0, /*walk=*/1));
   }
   return 0;
 }
@@ -303,6 +304,7 @@ int gpfit_fit_eval(gpfit_ctx* c, void* stream, const double* theta, const double
     return -2;
   }
   hipStream_t s = (hipStream_t)stream, sa = c->aux;
+  if (getenv("GPFIT_SINGLE_STREAM")) sa = s;
   const int n = (int)N, np = (int)round_up(N, TILE);
   const int dfull = n_rows * n_cols;
   if (np > c->np_cap || dfull > c->dfull_cap) {
@@ -371,10 +373,15 @@ int gpfit_fit_eval(gpfit_ctx* c, void* stream, const double* theta, const double
   GP_TRY(launch_frob_lower(c->Tbuf, ld, np, c->scal + 5, c->frob_part, s));
 
   if (want_grad) {
-    // W = 1/2 (K~^-1 - K~^-1 V K~^-1) = 1/2 (Li^T Li - Z Z^T),  Z = Li^T T
-    GP_TRY(gemm(s, 1, 1, np, np, np, 0.5, c->Libuf, ld, c->Libuf, ld, 0.0, c->Wbuf, ld, 1, 2, 1));
-    GP_TRY(gemm(s, 1, 1, np, np, np, 1.0, c->Libuf, ld, c->Tbuf, ld, 0.0, c->Zbuf, ld, 0, 2, 1));
-    GP_TRY(gemm(s, 0, 0, np, np, np, -0.5, c->Zbuf, ld, c->Zbuf, ld, 1.0, c->Wbuf, ld, 1, 0, 0));
+    // W = 1/2 (K~^-1 - K~^-1 V K~^-1) = 1/2 Li^T (I - T T^T) Li        (T = L^-1 L_V)
+    //   Q = I - T T^T   lower x upper, lower tiles only          N^3/3
+    //   R = Q Li        symmetric x lower                         N^3
+    //   W = 1/2 Li^T R  upper x dense, lower tiles only          N^3/3
+    GP_TRY(gemm(s, 0, 0, np, np, np, -1.0, c->Tbuf, ld, c->Tbuf, ld, 0.0, c->Wbuf, ld, 1, 1, 2, /*reverse=*/1));
+    GP_TRY(launch_add_diag(c->Wbuf, ld, np, 1.0, s));
+    GP_TRY(launch_symmetrize(c->Wbuf, ld, np, s));
+    GP_TRY(gemm(s, 1, 1, np, np, np, 1.0, c->Wbuf, ld, c->Libuf, ld, 0.0, c->Zbuf, ld, 0, 0, 1, /*walk=*/2));
+    GP_TRY(gemm(s, 1, 1, np, np, np, 0.5, c->Libuf, ld, c->Zbuf, ld, 0.0, c->Wbuf, ld, 1, 2, 0));
     GP_TRY(launch_adjoint(c->Wbuf, c->Cos, ld, c->bv, c->q, n, np, c->Abuf, c->upart, c->vpart, c->sumA_part, s));
     const int t64 = np / 64;
     GP_TRY(launch_adjoint_reduce(c->upart, c->vpart, c->sumA_part, t64, t64 * (t64 + 1) / 2, c->q, c->wl, n, np,

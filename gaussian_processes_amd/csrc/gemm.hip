@@ -9,12 +9,17 @@ __global__ __launch_bounds__(GEMM_THREADS, (T == 128 ? 2 : 4)) void dgemm_mfma_k
                                                                                       int ntiles) {
   __shared__ __attribute__((aligned(16))) double smem[4 * KTILE * T];
 
-  // heaviest tiles first: with triangular operands the k range grows with the tile index,
-  // so the grid is walked backwards when `reverse` is set (shorter tail).
-  const int bid = p.reverse ? (ntiles - 1 - (int)blockIdx.x) : (int)blockIdx.x;
+  // heaviest tiles first: with triangular operands the k range depends on the tile position,
+  // so the launcher asks for the walk that starts with the long ones (shorter tail):
+  // bit 0 = walk backwards, bit 1 = column-major (dense output only).
+  const int bid = (p.reverse & 1) ? (ntiles - 1 - (int)blockIdx.x) : (int)blockIdx.x;
   int ti, tj;
   if (p.out_lower) {
     lower_tile(bid, TILE / T, ti, tj);
+  } else if (p.reverse & 2) {
+    const int tiles_m = ntiles / tiles_n;
+    tj = bid / tiles_m;
+    ti = bid % tiles_m;
   } else {
     ti = bid / tiles_n;
     tj = bid % tiles_n;

@@ -86,5 +86,6 @@ int launch_dq(const double* Xt, const double* XDt, int64_t ld, int dp, int n, co
 int launch_dk_metric(double* H, int64_t ldh, const double* Cos, int64_t ldc, const double* q1, const double* q2,
                      const double* dq1, const double* dq2, int n1, int n2, hipStream_t s);
 int launch_fill(double* x, int64_t n, double v, hipStream_t s);
+int launch_add_diag(double* A, int64_t lda, int n, double v, hipStream_t s);
 
 }  // namespace gpfit
