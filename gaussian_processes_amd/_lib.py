@@ -16,6 +16,7 @@ _SIGS = {
     "gpfit_version": (i32, []),
     "gpfit_last_error": (ctypes.c_char_p, []),
     "gpfit_dgemm": (i32, [vp, i32, i32, i32, i32, i32, f64, vp, i64, vp, i64, f64, vp, i64, i32, i32, i32]),
+    "gpfit_dgemm_ex": (i32, [vp, i32, i32, i32, i32, i32, f64, vp, i64, vp, i64, f64, vp, i64, i32, i32, i32, i32, i32]),
     "gpfit_ctx_create": (i32, [i32, i64, i64, i64, ctypes.POINTER(vp)]),
     "gpfit_ctx_destroy": (None, [vp]),
     "gpfit_check_limits": (i32, [pd, pd, pd]),

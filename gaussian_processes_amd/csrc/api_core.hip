@@ -13,9 +13,20 @@ int gpfit_version(void) { return GPFIT_VERSION; }
 
 const char* gpfit_last_error(void) { return gpfit::g_err.c_str(); }
 
+int gpfit_dgemm_ex(void* stream, int a_kmajor, int b_kmajor, int M, int N, int K, double alpha,
+                   const double* A, int64_t lda, const double* B, int64_t ldb, double beta, double* C,
+                   int64_t ldc, int out_lower, int a_tri, int b_tri, int walk, int tile);
+
 int gpfit_dgemm(void* stream, int a_kmajor, int b_kmajor, int M, int N, int K, double alpha,
                 const double* A, int64_t lda, const double* B, int64_t ldb, double beta, double* C,
                 int64_t ldc, int out_lower, int a_tri, int b_tri) {
+  return gpfit_dgemm_ex(stream, a_kmajor, b_kmajor, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, out_lower,
+                        a_tri, b_tri, 0, 0);
+}
+
+int gpfit_dgemm_ex(void* stream, int a_kmajor, int b_kmajor, int M, int N, int K, double alpha,
+                   const double* A, int64_t lda, const double* B, int64_t ldb, double beta, double* C,
+                   int64_t ldc, int out_lower, int a_tri, int b_tri, int walk, int tile) {
   if ((M & 1) || (N & 1)) {
     gpfit::set_error("gpfit_dgemm: M and N must be even");
     return -3;
@@ -27,7 +38,7 @@ int gpfit_dgemm(void* stream, int a_kmajor, int b_kmajor, int M, int N, int K, d
   g.alpha = alpha; g.beta = beta;
   g.a_kmajor = a_kmajor; g.b_kmajor = b_kmajor;
   g.out_lower = out_lower; g.a_tri = a_tri; g.b_tri = b_tri;
-  g.batch = 1; g.split_k = 1;
+  g.batch = 1; g.split_k = 1; g.reverse = walk; g.tile = tile;
   return gpfit::launch_gemm(g, (hipStream_t)stream);
 }
 

@@ -21,6 +21,7 @@
 // recorded with atomicCAS on *info (0 = none so far); the block is then completed with the
 // offending pivot replaced by 1 so that no NaN/Inf propagates into later kernels.
 #include "common.h"
+#include <cstdlib>
 
 namespace gpfit {
 
@@ -47,15 +48,29 @@ __device__ __forceinline__ void tri_decode(int t, int& a, int& b) {  // t -> (a,
 __global__ __launch_bounds__(LEAF_THREADS) void chol_leaf_kernel(const double* __restrict__ A, int64_t lda,
                                                                  double* __restrict__ L, int64_t ldl,
                                                                  double* __restrict__ Linv, int64_t ldi,
-                                                                 int* __restrict__ info, int info_base) {
+                                                                 int* __restrict__ info, int info_base, int dbg) {
   extern __shared__ __attribute__((aligned(16))) double S[];  // [128][130] + rdiag[128]
   double* rdiag = S + LEAF * LLD;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int fr = lane & 15, fq = lane >> 4;
 
-  for (int e = tid; e < LEAF * LEAF; e += LEAF_THREADS) {
-    const int i = e >> 7, j = e & 127;
-    S[i * LLD + j] = (j <= i) ? A[(int64_t)i * lda + j] : 0.0;
+  // the block is read with all 32 row segments of a thread in flight at once (a rolled loop
+  // would pay one L2/HBM round trip per row: ~20 us of pure latency on the critical path)
+  {
+    double2 v[32];
+#pragma unroll
+    for (int it = 0; it < 32; ++it) {
+      const int e = tid + it * LEAF_THREADS;
+      const int i = e >> 6, j = (e & 63) * 2;
+      v[it] = (j <= i) ? *reinterpret_cast<const double2*>(A + (int64_t)i * lda + j) : make_double2(0.0, 0.0);
+    }
+#pragma unroll
+    for (int it = 0; it < 32; ++it) {
+      const int e = tid + it * LEAF_THREADS;
+      const int i = e >> 6, j = (e & 63) * 2;
+      if (j + 1 > i) v[it].y = 0.0;
+      *reinterpret_cast<double2*>(S + i * LLD + j) = v[it];
+    }
   }
   __syncthreads();
 
@@ -63,7 +78,7 @@ __global__ __launch_bounds__(LEAF_THREADS) void chol_leaf_kernel(const double* _
   for (int kb = 0; kb < 8; ++kb) {
     const int c0 = 16 * kb;
     // ---- (1) diagonal 16 x 16 block: one wave, one row per lane, readlane broadcasts
-    if (wave == 0) {
+    if (wave == 0 && !(dbg & 1)) {
       double v[16], rk[16];
 #pragma unroll
       for (int j = 0; j < 16; ++j) v[j] = (lane < 16) ? S[(c0 + lane) * LLD + c0 + j] : 0.0;
@@ -74,8 +89,14 @@ __global__ __launch_bounds__(LEAF_THREADS) void chol_leaf_kernel(const double* _
           if (lane == 0) atomicCAS(info, 0, info_base + c0 + k + 1);
           p = 1.0;
         }
-        const double dkk = sqrt(p);
-        const double rinv = 1.0 / dkk;
+        // 1/sqrt(p) from v_rsq_f64 + two Newton steps, sqrt(p) = p*y with one Heron correction:
+        // ~1/3 of the dependent latency of sqrt() followed by a division, same last-bit quality
+        double rinv = __builtin_amdgcn_rsq(p);
+        const double hp = 0.5 * p;
+        rinv = rinv * fma(-hp * rinv, rinv, 1.5);
+        rinv = rinv * fma(-hp * rinv, rinv, 1.5);
+        double dkk = p * rinv;
+        dkk = fma(fma(-dkk, dkk, p), 0.5 * rinv, dkk);
         rk[k] = rinv;
         v[k] = (lane == k) ? dkk : v[k] * rinv;
 #pragma unroll
@@ -96,7 +117,7 @@ __global__ __launch_bounds__(LEAF_THREADS) void chol_leaf_kernel(const double* _
     __syncthreads();
     // ---- (2) rows below the diagonal block: X * Ld^T = P, one row per lane
     const int m = LEAF - c0 - 16;
-    if (tid < m) {
+    if (tid < m && !(dbg & 2)) {
       const int row = c0 + 16 + tid;
       double x[16];
 #pragma unroll
@@ -114,7 +135,7 @@ __global__ __launch_bounds__(LEAF_THREADS) void chol_leaf_kernel(const double* _
     __syncthreads();
     // ---- (3) trailing rank-16 update of the 16 x 16 tiles (ta >= tb) on MFMA
     const int nt = 7 - kb, ntiles = nt * (nt + 1) / 2;
-    for (int t = wave; t < ntiles; t += 4) {
+    for (int t = wave; t < ((dbg & 4) ? 0 : ntiles); t += 4) {
       int ta, tb;
       tri_decode(t, ta, tb);
       const int i0 = c0 + 16 + 16 * ta, j0 = c0 + 16 + 16 * tb;
@@ -133,16 +154,20 @@ __global__ __launch_bounds__(LEAF_THREADS) void chol_leaf_kernel(const double* _
     __syncthreads();
   }
 
-  for (int e = tid; e < LEAF * LEAF; e += LEAF_THREADS) {
-    const int i = e >> 7, j = e & 127;
-    L[(int64_t)i * ldl + j] = (j <= i) ? S[i * LLD + j] : 0.0;
+  for (int e = tid; e < LEAF * LEAF / 2; e += LEAF_THREADS) {
+    const int i = e >> 6, j = (e & 63) * 2;
+    double2 v = *reinterpret_cast<const double2*>(S + i * LLD + j);
+    if (j > i) v.x = 0.0;
+    if (j + 1 > i) v.y = 0.0;
+    *reinterpret_cast<double2*>(L + (int64_t)i * ldl + j) = v;
   }
   __syncthreads();
 
   // ======================= in-place inverse of the lower factor =======================
   // (I1) the eight 16 x 16 diagonal blocks: forward substitution on the identity, one column
   //      per lane (lanes 0-15: block 2*wave, lanes 16-31: block 2*wave+1)
-  if (lane < 32) {
+  if (dbg & 32) return;
+  if (lane < 32 && !(dbg & 8)) {
     const int b0 = 16 * (2 * wave + (lane >> 4));
     const int j = lane & 15;
     double x[16];
@@ -162,7 +187,7 @@ __global__ __launch_bounds__(LEAF_THREADS) void chol_leaf_kernel(const double* _
   // (I2) merge levels: for each pair (X11, X22) of inverted s x s diagonal blocks at offset o,
   //      X21 = -X22 * (L21 * X11), 16 x 16 tiles on MFMA, product kept in registers between the
   //      two passes so the update is in place.
-  for (int s = 16; s <= 64; s *= 2) {
+  for (int s = 16; s <= ((dbg & 16) ? 0 : 64); s *= 2) {
     const int tps = s / 16;                  // tiles per side of one X21 block
     const int tiles_per_merge = tps * tps;
     const int total = (LEAF / (2 * s)) * tiles_per_merge;  // 4, 8, 16
@@ -239,9 +264,12 @@ __global__ __launch_bounds__(LEAF_THREADS) void chol_leaf_kernel(const double* _
     __syncthreads();
   }
 
-  for (int e = tid; e < LEAF * LEAF; e += LEAF_THREADS) {
-    const int i = e >> 7, j = e & 127;
-    Linv[(int64_t)i * ldi + j] = (j <= i) ? S[i * LLD + j] : 0.0;
+  for (int e = tid; e < LEAF * LEAF / 2; e += LEAF_THREADS) {
+    const int i = e >> 6, j = (e & 63) * 2;
+    double2 v = *reinterpret_cast<const double2*>(S + i * LLD + j);
+    if (j > i) v.x = 0.0;
+    if (j + 1 > i) v.y = 0.0;
+    *reinterpret_cast<double2*>(Linv + (int64_t)i * ldi + j) = v;
   }
 }
 
@@ -253,8 +281,10 @@ int launch_chol_leaf(const double* A, int64_t lda, double* L, int64_t ldl, doubl
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)LEAF_LDS_BYTES));
     attr_set = true;
   }
+  static int dbg = -1;
+  if (dbg < 0) dbg = getenv("GPFIT_LEAF_DBG") ? atoi(getenv("GPFIT_LEAF_DBG")) : 0;
   hipLaunchKernelGGL(chol_leaf_kernel, dim3(1), dim3(LEAF_THREADS), LEAF_LDS_BYTES, s, A, lda, L, ldl, Linv, ldi,
-                     info, info_base);
+                     info, info_base, dbg);
   GP_HIP(hipGetLastError());
   return 0;
 }
