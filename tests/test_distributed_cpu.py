@@ -1,0 +1,63 @@
+"""World-size-2 gloo test of the multi-GPU driver on CPU: X broadcast from rank 0, cyclic
+partition of independent cells, all-gather of (loss, grad[6]).  The per-unit evaluator here is
+the CPU oracle (the GPU evaluator needs a GPU); what is under test is the sharding logic."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from gaussian_processes_amd import multi, synthetic as syn
+from oracle import gp_oracle as orc
+
+N, D, CELLS = 48, 16, 5
+KEYS = syn.THETA_KEYS
+
+
+def eval_cell(X, cell):
+    lower, upper = syn.limits()
+    grid = syn.grid_for(D)
+    r_np, m_np = syn.cell_inputs(N, cell)
+    th0, th1 = syn.theta0(cell), syn.theta_eval(cell)
+    C0, mask0 = orc.spatial_metric(th0, lower, upper, grid)
+    V = 0.5 * orc.arccos_gram(th0, X[:, mask0], X[:, mask0], C0)
+    loss, grad = orc.mstep_closure_cholesky(th1, lower, upper, grid, X, torch.from_numpy(r_np), torch.from_numpy(m_np),
+                                            V, syn.F_PARAMS["logA"], syn.F_PARAMS["lambda0"])
+    return [loss] + [grad[k] for k in KEYS]
+
+
+def worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    X0 = torch.from_numpy(syn.stimuli(N, D)) if rank == 0 else None
+    X = multi.broadcast_stimuli(X0, (N, D), torch.device("cpu"))
+    table = multi.run_sharded(CELLS, lambda u: eval_cell(X, u), torch.device("cpu"))
+    np.save(os.path.join(out_dir, f"table_{rank}.npy"), table.numpy())
+    np.save(os.path.join(out_dir, f"x_{rank}.npy"), X.numpy())
+    dist.destroy_process_group()
+
+
+def test_partition_is_a_cyclic_cover():
+    for n, w in [(64, 8), (5, 2), (7, 4), (3, 8)]:
+        parts = [multi.partition(n, w, r) for r in range(w)]
+        assert sorted(sum(parts, [])) == list(range(n))
+        assert max(len(p) for p in parts) - min(len(p) for p in parts) <= 1
+    assert multi.partition(64, 8, 3) == list(range(3, 64, 8))
+
+
+def test_two_rank_gloo_shard_and_gather(tmp_path):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    t0, t1 = np.load(tmp_path / "table_0.npy"), np.load(tmp_path / "table_1.npy")
+    assert np.array_equal(t0, t1), "ranks disagree on the gathered table"
+    assert np.array_equal(np.load(tmp_path / "x_0.npy"), np.load(tmp_path / "x_1.npy")), "X broadcast failed"
+    X = torch.from_numpy(syn.stimuli(N, D))
+    ref = np.array([eval_cell(X, u) for u in range(CELLS)])
+    assert np.allclose(t0, ref, rtol=1e-12, atol=0)
+    assert np.all(np.isfinite(t0)) and len(np.unique(t0[:, 0])) == CELLS
