@@ -1,0 +1,116 @@
+// C-ABI entry points built on the recursive MFMA Cholesky: a standalone factorisation
+// (log_det, general solves of the drop-in module), the fused E-step Newton update and the
+// one-pass firing-rate-parameter evaluation.
+#include "context.h"
+#include "gpfit_mi355x.h"
+
+#include <cmath>
+
+using namespace gpfit;
+
+#define GP_TRY(expr)            \
+  do {                          \
+    int _rc = (expr);           \
+    if (_rc != 0) return _rc;   \
+  } while (0)
+
+static int gemm_full(hipStream_t s, int ak, int bk, int M, int N, int K, double alpha, const double* A, int64_t lda,
+                     const double* B, int64_t ldb, double beta, double* C, int64_t ldc, int lower, int at, int bt,
+                     int walk) {
+  GemmArgs g{};
+  g.A = A; g.B = B; g.C = C; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
+  g.M = M; g.N = N; g.K = K; g.alpha = alpha; g.beta = beta; g.a_kmajor = ak; g.b_kmajor = bk;
+  g.out_lower = lower; g.a_tri = at; g.b_tri = bt; g.batch = 1; g.split_k = 1; g.reverse = walk;
+  return launch_gemm(g, s);
+}
+
+extern "C" {
+
+int gpfit_potrf(gpfit_ctx* c, void* stream, const double* A, int64_t lda, int64_t n, double* L, int64_t ldl,
+                double* Linv, int64_t ldi, double* logdet_host, int* info_host) {
+  if (!c || !A || n <= 0) {
+    set_error("gpfit_potrf: bad argument");
+    return -3;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  const int np = (int)round_up(n, TILE);
+  if (np > c->np_cap) {
+    set_error("gpfit_potrf: matrix larger than the context capacity");
+    return -3;
+  }
+  const int64_t ld = np;
+  GP_HIP(hipMemsetAsync(c->info, 0, 4 * sizeof(int), s));
+  GP_TRY(launch_pack_lower(A, lda, (int)n, c->Kbuf, ld, np, s));
+  CholBufs b{c->Kbuf, c->Lbuf, c->Libuf, c->Tmp, ld, c->info};
+  GP_TRY(potrf_rec(b, 0, np, Linv != nullptr, s));
+  GP_TRY(launch_logdet(c->Lbuf, ld, (int)n, c->scal + 3, s));
+  if (L) GP_TRY(launch_unpack_tri(c->Lbuf, ld, (int)n, L, ldl, s));
+  if (Linv) GP_TRY(launch_unpack_tri(c->Libuf, ld, (int)n, Linv, ldi, s));
+  GP_HIP(hipMemcpyAsync(c->scal_host, c->scal, 8 * sizeof(double), hipMemcpyDeviceToHost, s));
+  GP_HIP(hipMemcpyAsync(c->info_host, c->info, 4 * sizeof(int), hipMemcpyDeviceToHost, s));
+  GP_HIP(hipStreamSynchronize(s));
+  if (logdet_host) *logdet_host = c->scal_host[3];
+  if (info_host) *info_host = c->info_host[0];
+  if (c->info_host[0] != 0) {
+    set_error("gpfit_potrf: matrix is not positive definite");
+    return c->info_host[0];
+  }
+  return 0;
+}
+
+int gpfit_estep(gpfit_ctx* c, void* stream, const double* K, int64_t ldk, int64_t N, const double* r,
+                const double* m, const double* f, double logA, double* m_new, double* V_new, int64_t ldv) {
+  if (!c || !K || !r || !m || !f || !m_new || !V_new || N <= 0) {
+    set_error("gpfit_estep: bad argument");
+    return -3;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  const int n = (int)N, np = (int)round_up(N, TILE);
+  if (np > c->np_cap) {
+    set_error("gpfit_estep: problem larger than the context capacity");
+    return -3;
+  }
+  const int64_t ld = np;
+  const double A = std::exp(logA);
+  double* sv = c->yv;
+  double* rhs = c->bv;
+  GP_HIP(hipMemsetAsync(c->info, 0, 4 * sizeof(int), s));
+  GP_TRY(launch_estep_prep(f, r, m, n, np, A, sv, rhs, s));
+  // M = I + S K S (lower), SK = S K (dense), Kl = K (lower)
+  GP_TRY(launch_estep_build(K, ldk, n, np, sv, c->Kbuf, c->Zbuf, c->Wbuf, ld, s));
+  CholBufs b{c->Kbuf, c->Lbuf, c->Libuf, c->Tmp, ld, c->info};
+  GP_TRY(potrf_rec(b, 0, np, true, s));
+  // T = L_M^-1 (S K)          lower x dense                         N^3
+  GP_TRY(gemm_full(s, 0, 1, np, np, np, 1.0, c->Libuf, ld, c->Zbuf, ld, 0.0, c->Abuf, ld, 0, 1, 0, 1));
+  // V = K - T^T T             lower tiles only                      N^3
+  GP_TRY(gemm_full(s, 1, 1, np, np, np, -1.0, c->Abuf, ld, c->Abuf, ld, 1.0, c->Wbuf, ld, 1, 0, 0, 0));
+  // m_new = V (A^2 f o m + A (r - f))                                utils.py:1431
+  GP_TRY(launch_symv_lower(c->Wbuf, ld, n, rhs, c->tvec, s));
+  GP_HIP(hipMemcpyAsync(m_new, c->tvec, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, s));
+  GP_TRY(launch_unpack_sym(c->Wbuf, ld, n, V_new, ldv, s));  // symmetric by construction (utils.py:1438)
+  GP_HIP(hipMemcpyAsync(c->info_host, c->info, 4 * sizeof(int), hipMemcpyDeviceToHost, s));
+  GP_HIP(hipStreamSynchronize(s));
+  if (c->info_host[0] != 0) {
+    set_error("gpfit_estep: I + S K S is not positive definite (is K_tilde symmetric positive definite?)");
+    return c->info_host[0];
+  }
+  return 0;
+}
+
+int gpfit_fparam_eval(gpfit_ctx* c, void* stream, const double* lam_m, const double* lam_var, const double* r,
+                      int64_t N, double logA, int closed_form_lambda0, double lambda0_in, double* f_out,
+                      double* out_host) {
+  if (!c || !lam_m || !lam_var || !r || !out_host || N <= 0) {
+    set_error("gpfit_fparam_eval: bad argument");
+    return -3;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  GP_TRY(launch_fparam(lam_m, lam_var, r, (int)N, std::exp(logA), closed_form_lambda0, lambda0_in, f_out,
+                       c->scal + 32, s));
+  GP_HIP(hipMemcpyAsync(c->scal_host + 32, c->scal + 32, 7 * sizeof(double), hipMemcpyDeviceToHost, s));
+  GP_HIP(hipStreamSynchronize(s));
+  for (int i = 0; i < 7; ++i) out_host[i] = c->scal_host[32 + i];
+  return 0;
+}
+
+}  // extern "C"

@@ -634,4 +634,152 @@ int launch_fill(double* x, int64_t n, double v, hipStream_t s) {
   return 0;
 }
 
+// ------------------------------------------------------------------ E-step helpers
+// s_i = A sqrt(f_i) ; rhs_i = A^2 f_i m_i + A (r_i - f_i)   (utils.py:1421-1422, 1431 with a = I)
+__global__ void estep_prep_kernel(const double* __restrict__ f, const double* __restrict__ r,
+                                  const double* __restrict__ m, int n, int np, double A, double* __restrict__ sv,
+                                  double* __restrict__ rhs) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= np) return;
+  if (i >= n) {
+    sv[i] = 0.0;
+    rhs[i] = 0.0;
+    return;
+  }
+  sv[i] = A * sqrt(f[i]);
+  rhs[i] = A * A * f[i] * m[i] + A * (r[i] - f[i]);
+}
+
+int launch_estep_prep(const double* f, const double* r, const double* m, int n, int np, double A, double* sv,
+                      double* rhs, hipStream_t s) {
+  hipLaunchKernelGGL(estep_prep_kernel, dim3((np + 255) / 256), dim3(256), 0, s, f, r, m, n, np, A, sv, rhs);
+  GP_HIP(hipGetLastError());
+  return 0;
+}
+
+// M = I + diag(s) K diag(s) (lower 128-tiles, identity padding), SK = diag(s) K (full, zero padded),
+// Kl = K (lower 128-tiles, zero padded) -- one pass over K
+__global__ void estep_build_kernel(const double* __restrict__ K, int64_t ldk, int n, const double* __restrict__ sv,
+                                   double* __restrict__ Mb, double* __restrict__ SK, double* __restrict__ Kl,
+                                   int64_t ld) {
+  const int tj = blockIdx.x, ti = blockIdx.y;
+  const int r0 = ti * TILE, c0 = tj * TILE;
+  for (int e = threadIdx.x; e < TILE * TILE; e += blockDim.x) {
+    const int i = r0 + (e >> 7), j = c0 + (e & 127);
+    const bool in = (i < n && j < n);
+    const double k = in ? K[(int64_t)i * ldk + j] : 0.0;
+    const double si = sv[i];
+    SK[(int64_t)i * ld + j] = si * k;
+    if (tj <= ti) {
+      Mb[(int64_t)i * ld + j] = si * k * sv[j] + ((i == j) ? 1.0 : 0.0);
+      Kl[(int64_t)i * ld + j] = k;
+    }
+  }
+}
+
+int launch_estep_build(const double* K, int64_t ldk, int n, int np, const double* sv, double* Mb, double* SK,
+                       double* Kl, int64_t ld, hipStream_t s) {
+  hipLaunchKernelGGL(estep_build_kernel, dim3(np / TILE, np / TILE), dim3(256), 0, s, K, ldk, n, sv, Mb, SK, Kl, ld);
+  GP_HIP(hipGetLastError());
+  return 0;
+}
+
+// y = A x for a symmetric matrix stored in its lower triangle (row-major): one wave per row
+// gathers the row part (j <= i) and the column part (j > i) of row i.
+__global__ void symv_lower_kernel(const double* __restrict__ A, int64_t lda, int n, const double* __restrict__ x,
+                                  double* __restrict__ y) {
+  const int lane = threadIdx.x & 63;
+  const int i = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (i >= n) return;
+  double v = 0.0;
+  for (int j = lane; j <= i; j += 64) v += A[(int64_t)i * lda + j] * x[j];
+  for (int j = i + 1 + lane; j < n; j += 64) v += A[(int64_t)j * lda + i] * x[j];
+  v = wave_sum(v);
+  if (lane == 0) y[i] = v;
+}
+
+int launch_symv_lower(const double* A, int64_t lda, int n, const double* x, double* y, hipStream_t s) {
+  hipLaunchKernelGGL(symv_lower_kernel, dim3((n + 3) / 4), dim3(256), 0, s, A, lda, n, x, y);
+  GP_HIP(hipGetLastError());
+  return 0;
+}
+
+// dst[n][ldd] (full symmetric) <- lower triangle of src[np][lds]
+__global__ void unpack_sym_kernel(const double* __restrict__ src, int64_t lds, int n, double* __restrict__ dst,
+                                  int64_t ldd) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y;
+  if (i >= n || j >= n) return;
+  dst[(int64_t)i * ldd + j] = (j <= i) ? src[(int64_t)i * lds + j] : src[(int64_t)j * lds + i];
+}
+
+int launch_unpack_sym(const double* src, int64_t lds, int n, double* dst, int64_t ldd, hipStream_t s) {
+  hipLaunchKernelGGL(unpack_sym_kernel, dim3((n + 255) / 256, n), dim3(256), 0, s, src, lds, n, dst, ldd);
+  GP_HIP(hipGetLastError());
+  return 0;
+}
+
+// dst[n][ldd] <- lower triangle of src, strict upper zeroed (triangular factor for the caller)
+__global__ void unpack_tri_kernel(const double* __restrict__ src, int64_t lds, int n, double* __restrict__ dst,
+                                  int64_t ldd) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y;
+  if (i >= n || j >= n) return;
+  dst[(int64_t)i * ldd + j] = (j <= i) ? src[(int64_t)i * lds + j] : 0.0;
+}
+
+int launch_unpack_tri(const double* src, int64_t lds, int n, double* dst, int64_t ldd, hipStream_t s) {
+  hipLaunchKernelGGL(unpack_tri_kernel, dim3((n + 255) / 256, n), dim3(256), 0, s, src, lds, n, dst, ldd);
+  GP_HIP(hipGetLastError());
+  return 0;
+}
+
+// ------------------------------------------------------------------ firing-rate parameters
+// One pass over the N training points for the inner logA optimiser (utils.py:1897-1934):
+//   e_i = exp(A lam_m_i + A^2/2 lam_var_i)
+//   lambda0 = closed form log(sum r) - log(sum e)            (utils.py:1215-1229) or the given one
+//   f_i = e_i exp(lambda0)                                   (utils.py:1138)
+//   loglik = A r.lam_m + lambda0 sum r - sum f               (utils.py:1243)
+//   dloglik/dlogA = A (r.lam_m - sum (lam_m + A lam_var) f)  (utils.py:1253)
+// out[0] lambda0 used, out[1] loglik, out[2] dloglik/dlogA, out[3] sum f, out[4] sum r, out[5] r.lam_m,
+// out[6] closed-form lambda0
+__global__ void fparam_kernel(const double* __restrict__ lam_m, const double* __restrict__ lam_var,
+                              const double* __restrict__ r, int n, double A, int closed_form, double lambda0_in,
+                              double* __restrict__ f, double* __restrict__ out) {
+  __shared__ double sh[17];
+  double se = 0.0, sr = 0.0, srm = 0.0, sg = 0.0;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    const double e = exp(A * lam_m[i] + 0.5 * A * A * lam_var[i]);
+    se += e;
+    sr += r[i];
+    srm += r[i] * lam_m[i];
+    sg += (lam_m[i] + A * lam_var[i]) * e;
+  }
+  se = block_sum(se, sh);
+  sr = block_sum(sr, sh);
+  srm = block_sum(srm, sh);
+  sg = block_sum(sg, sh);
+  const double lambda0 = closed_form ? (log(sr) - log(se)) : lambda0_in;
+  const double el0 = exp(lambda0);
+  if (f)
+    for (int i = threadIdx.x; i < n; i += blockDim.x)
+      f[i] = exp(A * lam_m[i] + 0.5 * A * A * lam_var[i] + lambda0);
+  if (threadIdx.x == 0) {
+    const double sf = se * el0;
+    out[0] = lambda0;
+    out[1] = A * srm + lambda0 * sr - sf;
+    out[2] = A * (srm - sg * el0);
+    out[3] = sf;
+    out[4] = sr;
+    out[5] = srm;
+    out[6] = log(sr) - log(se);  // closed-form lambda0 for this logA, whatever was used above
+  }
+}
+
+int launch_fparam(const double* lam_m, const double* lam_var, const double* r, int n, double A, int closed_form,
+                  double lambda0_in, double* f, double* out, hipStream_t s) {
+  hipLaunchKernelGGL(fparam_kernel, dim3(1), dim3(1024), 0, s, lam_m, lam_var, r, n, A, closed_form, lambda0_in, f,
+                     out);
+  GP_HIP(hipGetLastError());
+  return 0;
+}
+
 }  // namespace gpfit

@@ -88,4 +88,15 @@ int launch_dk_metric(double* H, int64_t ldh, const double* Cos, int64_t ldc, con
 int launch_fill(double* x, int64_t n, double v, hipStream_t s);
 int launch_add_diag(double* A, int64_t lda, int n, double v, hipStream_t s);
 
+// ---- E-step / factorisation / firing-rate helpers
+int launch_estep_prep(const double* f, const double* r, const double* m, int n, int np, double A, double* sv,
+                      double* rhs, hipStream_t s);
+int launch_estep_build(const double* K, int64_t ldk, int n, int np, const double* sv, double* Mb, double* SK,
+                       double* Kl, int64_t ld, hipStream_t s);
+int launch_symv_lower(const double* A, int64_t lda, int n, const double* x, double* y, hipStream_t s);
+int launch_unpack_sym(const double* src, int64_t lds, int n, double* dst, int64_t ldd, hipStream_t s);
+int launch_unpack_tri(const double* src, int64_t lds, int n, double* dst, int64_t ldd, hipStream_t s);
+int launch_fparam(const double* lam_m, const double* lam_var, const double* r, int n, double A, int closed_form,
+                  double lambda0_in, double* f, double* out, hipStream_t s);
+
 }  // namespace gpfit

@@ -26,6 +26,8 @@ from .synthetic import THETA_KEYS
 torch.set_grad_enabled(False)  # reference utils.py:2 (analytic gradients only)
 
 TORCH_DTYPE = torch.float64          # utils.py:31
+torch.set_default_dtype(TORCH_DTYPE)  # utils.py:33 -- the reference makes float64 the global default on
+#                                       import and its notebooks rely on it (torch.tensor(0.05) is fp64)
 MIN_TOLERANCE = 1.e-11               # utils.py:37
 EIGVAL_TOL = 1.e-4                   # utils.py:39 (module global read at call time, as in the reference)
 PI32 = 3.1415927410125732            # utils.py:25: float32-rounded pi
@@ -182,3 +184,790 @@ def acosker(theta, x1, x2=None, C=None, dC=None, diag=False):
     if dC is None:
         return K
     return K, {k: dK[i] for i, k in enumerate(THETA_KEYS)}
+
+
+# ------------------------------------------------------------------ dense helpers on the MFMA GEMM
+def _pad2(t, rows, cols):
+    if t.shape[0] == rows and t.shape[1] == cols and t.is_contiguous():
+        return t
+    out = torch.zeros((rows, cols), dtype=TORCH_DTYPE, device=t.device)
+    out[: t.shape[0], : t.shape[1]] = t
+    return out
+
+
+def _ceil(x, m):
+    return (x + m - 1) // m * m
+
+
+def matmul(A, B, transA=False, transB=False, alpha=1.0):
+    """``alpha * op(A) @ op(B)`` on the fp64 MFMA GEMM (``gpfit_dgemm``): the torch ``@`` call
+    sites of the reference's path.  1-D operands are treated as column/row vectors."""
+    lib = _lib.load()
+    A, B = _cu(A), _cu(B)
+    va, vb = A.dim() == 1, B.dim() == 1
+    if va:
+        A = A[None, :] if not transA else A[:, None]
+    if vb:
+        B = B[:, None] if not transB else B[None, :]
+    M, K = (A.shape[1], A.shape[0]) if transA else A.shape
+    K2, N = (B.shape[1], B.shape[0]) if transB else B.shape
+    if K != K2:
+        raise RuntimeError(f"matmul: inner dimensions differ ({K} vs {K2})")
+    Kp, Mp, Np = _ceil(K, 16), _ceil(M, 2), _ceil(N, 2)
+    Ap = _pad2(A, Kp, Mp) if transA else _pad2(A, Mp, Kp)
+    Bp = _pad2(B, Np, Kp) if transB else _pad2(B, Kp, Np)
+    Cp = torch.empty((Mp, Np), dtype=TORCH_DTYPE, device=A.device)
+    _lib.check(lib.gpfit_dgemm(_stream(), 1 if transA else 0, 0 if transB else 1, Mp, Np, Kp, float(alpha),
+                               Ap.data_ptr(), Ap.stride(0), Bp.data_ptr(), Bp.stride(0), 0.0, Cp.data_ptr(),
+                               Cp.stride(0), 0, 0, 0), "gpfit_dgemm")
+    C = Cp[:M, :N]
+    if va and vb:
+        return C.reshape(()).clone()
+    if vb:
+        return C[:, 0].contiguous()   # never hand out strided views: callers pass data_ptr() on
+    if va:
+        return C[0, :].contiguous()
+    return C.contiguous()
+
+
+def cholesky(M, want_inverse=False):
+    """Lower Cholesky factor (and optionally its inverse) by the recursive MFMA algorithm.
+    Returns ``(L, Linv_or_None, logdet, info)``; info > 0 = first non-positive pivot (LAPACK)."""
+    lib = _lib.load()
+    M = _cu(M)
+    n = M.shape[0]
+    eng = get_engine(n, 1)
+    L = torch.empty((n, n), dtype=TORCH_DTYPE, device=M.device)
+    Li = torch.empty((n, n), dtype=TORCH_DTYPE, device=M.device) if want_inverse else None
+    logdet = ctypes.c_double()
+    info = ctypes.c_int()
+    rc = lib.gpfit_potrf(eng._ctx, _stream(), M.data_ptr(), M.stride(0), n, L.data_ptr(), L.stride(0),
+                         Li.data_ptr() if want_inverse else None, Li.stride(0) if want_inverse else 0,
+                         ctypes.byref(logdet), ctypes.byref(info))
+    if rc < 0:
+        _lib.check(rc, "gpfit_potrf")
+    return L, Li, float(logdet.value), int(info.value)
+
+
+def spd_inverse(M):
+    """M^-1 = L^-T L^-1 for a symmetric positive definite matrix (replaces the LU
+    ``torch.linalg.solve(M, I)`` of utils.py:2067)."""
+    L, Li, _, info = cholesky(M, want_inverse=True)
+    if info != 0:
+        raise torch.linalg.LinAlgError(f"spd_inverse: matrix is not positive definite (info={info})")
+    return matmul(Li, Li, transA=True)
+
+
+# ------------------------------------------------------------------ numeric guards (utils.py:633-685)
+def is_simmetric(tensor, name='M'):
+    difference = (tensor - tensor.T).abs()
+    if bool(torch.any(difference > MIN_TOLERANCE)):
+        print(f'Matrix {name} is not symmetric, maximum difference is {difference.max()}')
+        return False
+    return True
+
+
+def is_posdef(tensor, name='M'):
+    if not is_simmetric(tensor, name=name):
+        warnings.warn('The matrix is not symmetric, cannot check if it is positive definite')
+        return False
+    smallest = float(torch.linalg.eigvalsh(_cu(tensor)).min())
+    if smallest <= 0.:
+        warnings.warn(f'Matrix {name} is simmetric but has an eigenvalue smaller than 0 ')
+        return False
+    if smallest <= MIN_TOLERANCE:
+        warnings.warn(f'Matrix {name} is simmetric but has an eigenvalue smaller than MIN_TOLERANCE: {MIN_TOLERANCE}')
+        return False
+    return True
+
+
+def safe_log(x):
+    if bool(torch.any(x <= 0)):
+        raise ValueError("Negative or zero input to log detected")
+    if bool(torch.any(x < 1e-10)):
+        raise ValueError("Very small input to log detected")
+    return torch.log(x)
+
+
+def safe_acos(x):
+    if bool(torch.any(x > 1 - 1e-6)) or bool(torch.any(x < -1 + 1e-6)):
+        x = torch.clamp(x, -1 + 1e-6, 1 - 1e-6)
+    return torch.acos(x)
+
+
+def log_det(M, name='M', ignore_warning=False):
+    """log|M| from the Cholesky factor, with the reference's fallbacks (utils.py:1271-1304):
+    failed factorisation + symmetric -> sum of log of the eigenvalues above the truncation
+    rule (with warnings); not symmetric -> warning and 0."""
+    M = _cu(M)
+    L, _, logdet, info = cholesky(M)
+    if info == 0:
+        safe_log(torch.diagonal(L))  # raises exactly when the reference's safe_log would
+        return torch.tensor(logdet, dtype=TORCH_DTYPE, device=M.device)
+    if is_simmetric(M, name=name):
+        eigenvalues = torch.linalg.eigvalsh(M)
+        ikeep = eigenvalues > max(float(eigenvalues.max()) * EIGVAL_TOL, EIGVAL_TOL)
+        if not ignore_warning:
+            smallest = float(eigenvalues.min())
+            warnings.warn(f"Matrix {name} in logdet is simmetric but not posdef, using eigendecomposition to calculate the log determinant")
+            if smallest <= 0.:
+                warnings.warn(f'Matrix {name} in logdet is simmetric but has an eigenvalue smaller than 0 ')
+            elif smallest <= 1.e-10:
+                warnings.warn(f'Matrix {name} in logdet is simmetric but has an eigenvalue smaller than 1e-10 ')
+        return torch.sum(safe_log(eigenvalues[ikeep]))
+    warnings.warn(f"Matrix {name} in logdet is not simmetric in log_det used in KL_divergence")
+    return 0
+
+
+# ------------------------------------------------------------------ moments / likelihood / KL
+def lambda_moments(x, K_tilde, KKtilde_inv, Kvec, K, C, m, V, theta, kernfun=None, dK=None, dK_tilde=None,
+                   dK_vec=None, K_tilde_inv=None):
+    """Mean and variance of lambda at the training points and, optionally, their
+    theta-gradients (reference utils.py:1072-1124); every product on the MFMA GEMM."""
+    a = _cu(KKtilde_inv)
+    K, m, V = _cu(K), _cu(m), _cu(V)
+    lambda_m = matmul(a, m)                                                       # :1090
+    if Kvec is None:
+        Kvec = kernfun(theta, x, x2=None, C=C, dC=None, diag=True)                # :1094
+    aV = matmul(a, V)
+    lambda_var = _cu(Kvec) + torch.sum(-K * a + a * aV, 1)                        # :1101 (V symmetric)
+    if dK is None or dK_tilde is None or dK_vec is None or K_tilde_inv is None:
+        return lambda_m, lambda_var
+    dlambda_m, dlambda_var = {}, {}
+    Kinv = _cu(K_tilde_inv)
+    for key in dK.keys():
+        da = matmul(_cu(dK[key]) - matmul(a, dK_tilde[key]), Kinv)                # :1114
+        dlambda_m[key] = matmul(da, m)                                            # :1117
+        dlambda_var[key] = (_cu(dK_vec[key]) + 2 * torch.sum(da * aV, 1) - torch.sum(_cu(dK[key]) * a, 1)
+                            - torch.sum(K * da, 1))                               # :1120
+    return lambda_m, lambda_var, dlambda_m, dlambda_var
+
+
+def _lambda0_of(f_params):
+    return torch.exp(f_params['loglambda0']) if 'loglambda0' in f_params else f_params['lambda0']
+
+
+def _fparam_eval(lambda_m, lambda_var, r, logA, closed_form, lambda0=0.0, want_f=True):
+    lib = _lib.load()
+    lm, lv = _cu(lambda_m), _cu(lambda_var)
+    n = lm.shape[0]
+    rr = _cu(r) if r is not None else torch.zeros(n, dtype=TORCH_DTYPE, device=lm.device)
+    eng = get_engine(n, 1)
+    f = torch.empty(n, dtype=TORCH_DTYPE, device=lm.device) if want_f else None
+    out = (ctypes.c_double * 7)()
+    _lib.check(lib.gpfit_fparam_eval(eng._ctx, _stream(), lm.data_ptr(), lv.data_ptr(), rr.data_ptr(), n,
+                                     _scalar(logA), 1 if closed_form else 0, float(lambda0),
+                                     f.data_ptr() if want_f else None, out), "gpfit_fparam_eval")
+    return f, list(out)
+
+
+def mean_f_given_lambda_moments(f_params, lambda_m, lambda_var):
+    """<f> = exp(A <lambda> + A^2/2 Var(lambda) + lambda0)   (utils.py:1126-1141)."""
+    f, _ = _fparam_eval(lambda_m, lambda_var, None, f_params['logA'], False, _scalar(_lambda0_of(f_params)))
+    return f
+
+
+def lambda0_given_logA(logA, r, lambda_m, lambda_var):
+    """Closed-form optimum of lambda0 given A (utils.py:1215-1229)."""
+    _, out = _fparam_eval(lambda_m, lambda_var, r, logA, True, want_f=False)
+    return torch.tensor(out[0], dtype=TORCH_DTYPE)
+
+
+def mean_f(f_params, calculate_moments, lambda_m=None, lambda_var=None, x=None, K_tilde=None, KKtilde_inv=None,
+           Kvec=None, K=None, C=None, m=None, V=None, V_inv=None, theta=None, kernfun=None, dK=None, dK_tilde=None,
+           dK_vec=None, K_tilde_inv=None, r=None):
+    """utils.py:1143-1213: firing-rate mean, computing the lambda moments first when asked to."""
+    def rate(lm, lv):
+        if r is not None:
+            tmp = {'logA': f_params['logA'], 'lambda0': lambda0_given_logA(f_params['logA'], r, lm, lv)}
+            return mean_f_given_lambda_moments(tmp, lm, lv)
+        return mean_f_given_lambda_moments(f_params, lm, lv)
+
+    if calculate_moments and (lambda_m is None or lambda_var is None):
+        if dK is not None and dK_tilde is not None and dK_vec is not None and K_tilde_inv is not None:
+            lambda_m, lambda_var, dlm, dlv = lambda_moments(x, K_tilde, KKtilde_inv, Kvec, K, C, m, V, theta,
+                                                            kernfun=kernfun, dK=dK, dK_tilde=dK_tilde, dK_vec=dK_vec,
+                                                            K_tilde_inv=K_tilde_inv)
+            return rate(lambda_m, lambda_var), lambda_m, lambda_var, dlm, dlv
+        lambda_m, lambda_var = lambda_moments(x, K_tilde, KKtilde_inv, Kvec, K, C, m, V, theta, kernfun=kernfun)
+        return rate(lambda_m, lambda_var), lambda_m, lambda_var
+    return rate(lambda_m, lambda_var)
+
+
+def compute_loglikelihood(r, f_mean, lambda_m, lambda_var, f_params, compute_grad_for_f_params=False,
+                          dlambda_m=None, dlambda_var=None):
+    """utils.py:1231-1269.  O(N) reductions of device vectors (host-side glue)."""
+    r, f_mean, lambda_m, lambda_var = _cu(r), _cu(f_mean), _cu(lambda_m), _cu(lambda_var)
+    A = math.exp(_scalar(f_params['logA']))
+    lambda0 = _scalar(_lambda0_of(f_params))
+    rlambda_m = torch.dot(r, lambda_m)
+    sum_r = torch.sum(r)
+    loglikelihood = A * rlambda_m + lambda0 * sum_r - torch.sum(f_mean)           # :1243
+    if compute_grad_for_f_params:
+        d = {'logA': A * (rlambda_m - torch.dot(lambda_m + A * lambda_var, f_mean))}   # :1253
+        if 'loglambda0' in f_params:
+            d['loglambda0'] = (sum_r - torch.sum(f_mean)) * lambda0               # :1254
+        elif 'lambda0' in f_params:
+            d['lambda0'] = sum_r - torch.sum(f_mean)                              # :1255
+        return loglikelihood, d
+    if dlambda_m is not None and dlambda_var is not None:
+        d = {}
+        for key in dlambda_m.keys():
+            d[key] = (A * torch.dot(r, dlambda_m[key]) - A * torch.dot(f_mean, dlambda_m[key])
+                      - 0.5 * A * A * torch.dot(f_mean, dlambda_var[key]))        # :1266
+        return loglikelihood, d
+    return loglikelihood, rlambda_m, sum_r
+
+
+def compute_KL_div(m, V, K_tilde, K_tilde_inv, dK_tilde=None, ignore_warning=False):
+    """KL(q || p) and its theta-gradients (utils.py:1306-1337); no -n/2 term (:1326)."""
+    m, V, K_tilde, K_tilde_inv = _cu(m), _cu(V), _cu(K_tilde), _cu(K_tilde_inv)
+    c = matmul(V, K_tilde_inv)                                                    # :1318
+    b = matmul(K_tilde_inv, m)                                                    # :1320
+    KL = (-0.5 * log_det(V, name='V', ignore_warning=ignore_warning) + 0.5 * log_det(K_tilde, name='K_tilde')
+          + 0.5 * torch.dot(m, b) + 0.5 * torch.trace(c))                         # :1326
+    if dK_tilde is None:
+        return KL
+    dKL = {}
+    for key in dK_tilde.keys():
+        Bk = matmul(dK_tilde[key], K_tilde_inv)                                   # :1331
+        dKL[key] = 0.5 * torch.trace(Bk) - 0.5 * torch.sum(c * Bk.T) - 0.5 * torch.dot(b, matmul(Bk, m))  # :1333
+    return KL, dKL
+
+
+def Estep(r, KKtilde_inv, m, f_params, f_mean, K_tilde=None, K_tilde_inv=None, V=None, update_V_inv=False, alpha=1):
+    """Newton update of (m, V) -- the supported branch of the reference (alpha = 1,
+    update_V_inv=False; utils.py:1420-1439).  ``V = (I + K~ G)^-1 K~`` is evaluated in its
+    symmetric form ``L (I + L^T G L)^-1 L^T`` (K~ = L L^T) with two MFMA Cholesky factorisations
+    instead of the reference's LU solve.  The alpha != 1 / update_V_inv branches are documented
+    as not to be used (reference docs.md:5-7) and are not provided."""
+    if update_V_inv or K_tilde is None or alpha != 1:
+        warnings.warn('Estep: only the alpha = 1, update_V_inv = False update on V is implemented')
+        raise NotImplementedError
+    r, a, m, f_mean, K_tilde = _cu(r), _cu(KKtilde_inv), _cu(m), _cu(f_mean), _cu(K_tilde)
+    A = math.exp(_scalar(f_params['logA']))
+    g = A * matmul(a, r - f_mean, transA=True)                                    # :1421
+    G = A * A * matmul(a, a * f_mean[:, None], transA=True)                       # :1422
+    n = K_tilde.shape[0]
+    L, _, _, info = cholesky(K_tilde)
+    if info != 0:
+        raise torch.linalg.LinAlgError(f"Estep: K_tilde is not positive definite (info={info})")
+    W = matmul(L, matmul(G, L), transA=True)
+    W = (W + W.T) * 0.5 + torch.eye(n, dtype=TORCH_DTYPE, device=W.device)
+    _, Lwi, _, info = cholesky(W, want_inverse=True)
+    if info != 0:
+        raise torch.linalg.LinAlgError(f"Estep: I + L^T G L is not positive definite (info={info})")
+    P = matmul(L, Lwi, transB=True)
+    V_new = matmul(P, P, transB=True)                                             # = solve(I + K~G, K~), :1430
+    m_new = matmul(V_new, matmul(G, m) + g)                                       # :1431
+    V_new = (V_new + V_new.T) / 2                                                 # :1438
+    return m_new, V_new
+
+
+# ------------------------------------------------------------------ inference
+def lambda_moments_star(xstar, xtilde, C, theta, K_tilde, K_tilde_inv, m, V, B, kernfun):
+    """Predictive moments of lambda at test points (utils.py:1476-1500).  ``xstar`` may hold
+    several rows: the reference's one-row-at-a-time loop (utils.py:388-397) is batched."""
+    if kernfun == 'acosker':
+        kernfun = acosker
+    elif not callable(kernfun):
+        raise Exception('Kernel function not recognized')
+    Kvec_star = kernfun(theta, xstar, xtilde, C=C, dC=None, diag=False)          # :1486
+    Kvec_star = matmul(Kvec_star, B)                                              # :1487
+    a = matmul(Kvec_star, K_tilde_inv)                                            # :1489
+    mu_star = matmul(a, m)                                                        # :1491
+    K_star = kernfun(theta, xstar, x2=None, C=C, dC=None, diag=True)              # :1494
+    sigma_star2 = K_star + torch.sum(matmul(a, _cu(V) - _cu(K_tilde)) * a, 1)     # :1498
+    return mu_star, torch.reshape(sigma_star2, (_cu(xstar).reshape(-1, _cu(xstar).shape[-1]).shape[0],))
+
+
+# ------------------------------------------------------------------ initialisation (utils.py:705-857)
+def generate_xtilde(ntilde, x):
+    """Jittered random subset of the first ``ntilde`` stimuli (utils.py:705-711)."""
+    x = _cu(x)
+    idx = torch.randperm(ntilde, device=x.device)
+    first = x[idx, :]
+    return first + torch.finfo(TORCH_DTYPE).eps * 10 * torch.randn(first.shape, dtype=TORCH_DTYPE, device=x.device)
+
+
+def logbetaexpr_to_beta(logbetaexpr):
+    return torch.exp(-0.5 * torch.as_tensor(logbetaexpr)) * torch.tensor(0.5)
+
+
+def logrhoexpr_to_rho(logrhoexpr):
+    return torch.exp(-0.5 * torch.as_tensor(logrhoexpr)) / torch.sqrt(torch.tensor(2.0))
+
+
+def fromlogbetasam_to_logbetaexpr(logbetasam):
+    return logbetasam - torch.log(torch.tensor(2.0))
+
+
+def fromlogrhosam_to_logrhoexpr(logrhosam):
+    return logrhosam - torch.log(torch.tensor(2.0))
+
+
+def get_sta(x, r, n_px_side):
+    """Spike-triggered average, its (hand-set) variance and the pixel of its peak (utils.py:736-753)."""
+    x, r = _cu(x), _cu(r)
+    n = r.shape[0]
+    img_mean = matmul(x, torch.ones_like(r), transA=True) / n
+    sta = matmul(x, r, transA=True) / n - img_mean
+    rows, cols = _grid(n_px_side)
+    peak = int(torch.argmax(torch.abs(sta)))
+    return sta, torch.tensor(10), (torch.tensor(peak // cols), torch.tensor(peak % cols))
+
+
+def generate_theta(x, r, n_px_side, display_hyper=False, **kwargs):
+    """Initial hyperparameters and their boxes (utils.py:755-857).  As in the reference the
+    receptive-field centre starts at (0, 0), the width is the hand-set 10 px^2, and caller
+    overrides in ``kwargs`` are applied only when ``display_hyper`` is true (utils.py:829-834)."""
+    up_lim, low_lim = 1, -1
+    rows, _ = _grid(n_px_side)
+    sigma_0 = torch.tensor(1.0, dtype=TORCH_DTYPE, requires_grad=True)
+    Amp = torch.tensor(1.0, dtype=TORCH_DTYPE, requires_grad=True)
+    get_sta(x, r, n_px_side)  # evaluated for parity of side effects; its peak is not used (utils.py:785-797)
+    eps_0x = torch.tensor(0.0, dtype=TORCH_DTYPE, requires_grad=True)
+    eps_0y = torch.tensor(0.0, dtype=TORCH_DTYPE, requires_grad=True)
+    beta = (torch.sqrt(torch.tensor(10.0, dtype=TORCH_DTYPE)) / rows) * (up_lim - low_lim)
+    logbetaexpr = (-2 * safe_log(2 * beta)).requires_grad_(True)
+    rho = beta / 2
+    logrhoexpr = (-safe_log(torch.tensor(2.0, dtype=TORCH_DTYPE) * (rho * rho))).requires_grad_(True)
+    theta = {'sigma_0': sigma_0, 'eps_0x': eps_0x, 'eps_0y': eps_0y, '-2log2beta': logbetaexpr,
+             '-log2rho2': logrhoexpr, 'Amp': Amp}
+    if display_hyper:
+        for key, value in kwargs.items():
+            if key in theta:
+                theta[key] = value
+                print(f'updated {key} to {_scalar(value):.4f}')
+        print(f' Dict of learnable hyperparameters : {", ".join(f"{k} = {_scalar(v):.4f}" for k, v in theta.items())}')
+        print(f' Hyperparameters from the logexpr  : beta = {float(logbetaexpr_to_beta(logbetaexpr)):.4f}, '
+              f'rho = {float(logrhoexpr_to_rho(logrhoexpr)):.4f}')
+    inf = float('inf')
+    lower = {'sigma_0': 0, 'eps_0x': low_lim, 'eps_0y': low_lim, '-2log2beta': -inf, '-log2rho2': -inf, 'Amp': 0.}
+    upper = {'sigma_0': inf, 'eps_0x': up_lim, 'eps_0y': up_lim, '-2log2beta': inf, '-log2rho2': inf, 'Amp': inf}
+    return (theta, lower, upper)
+
+
+def print_hyp(theta):
+    for key in theta.keys():
+        extra = ''
+        if key == '-2log2beta':
+            extra = f' --> beta: {float(logbetaexpr_to_beta(theta[key])):8.4f}'
+        if key == '-log2rho2':
+            extra = f' --> rho : {float(logrhoexpr_to_rho(theta[key])):8.4f}'
+        print(f' {key:<12}: {_scalar(theta[key]):>8.4f}{extra}')
+
+
+# ------------------------------------------------------------------ metric (utils.py:1502-1541)
+def explained_variance(rtst, f_pred, sigma=True):
+    """Reliability-normalised r^2 between predicted rates and repeated test responses
+    (rtst[repetitions, images]); with ``sigma`` a 1000-fold bootstrap over repetitions
+    (torch RNG -- reporting only, not part of the GP arithmetic)."""
+    rtst, f_pred = _cu(rtst), _cu(f_pred)
+
+    def r2_of(reven, rodd):
+        rel = torch.abs(torch.corrcoef(torch.stack((reven, rodd))))[0, 1]
+        acc_o = torch.corrcoef(torch.stack((f_pred, rodd)))[0, 1]
+        acc_e = torch.corrcoef(torch.stack((f_pred, reven)))[0, 1]
+        return 0.5 * (acc_o + acc_e) / rel
+
+    if not sigma:
+        return r2_of(torch.mean(rtst[0::2, :], 0), torch.mean(rtst[1::2, :], 0)), None
+    nboot, n = 1000, rtst.shape[0]
+    vals = torch.zeros(nboot, dtype=TORCH_DTYPE, device=rtst.device)
+    for i in range(nboot):
+        perm = torch.randperm(n, device=rtst.device)
+        vals[i] = r2_of(torch.mean(rtst[perm[0::2], :], 0), torch.mean(rtst[perm[1::2], :], 0))
+    return torch.mean(vals), torch.std(vals)
+
+
+# ------------------------------------------------------------------ fit (utils.py:1568-2316)
+def _eigen_stabilise(K_tilde):
+    """Spectral truncation of the reference (utils.py:1682-1683): eigh, keep
+    lambda > max(lambda_max * EIGVAL_TOL, EIGVAL_TOL).  torch.linalg.eigh is host plumbing here
+    (rank decision + basis), not part of the timed path."""
+    eigvals, eigvecs = torch.linalg.eigh(K_tilde, UPLO='L')
+    ikeep = eigvals > max(float(eigvals.max()) * EIGVAL_TOL, EIGVAL_TOL)
+    return eigvals, eigvecs, ikeep
+
+
+def _closure_general(theta, lims, n_px_side, x, xtilde, r, B, m_b, V_b, f_params, ntilde, nt):
+    """The M-step closure body in the reference's own B-projected formulation
+    (utils.py:2030-2099) on the GPU primitives: used when eigenvalues were truncated
+    (n < n_tilde) or n_tilde != n_t, where the original-basis fast path does not apply."""
+    lower, upper = lims
+    C, mask, dC = localker(theta=theta, theta_higher_lims=upper, theta_lower_lims=lower, n_px_side=n_px_side, grad=True)
+    xt_m = xtilde[:, mask].contiguous()
+    K_tilde, dK_tilde = acosker(theta, xt_m, xt_m, C=C, dC=dC, diag=False)
+    if ntilde != nt:
+        x_m = x[:, mask].contiguous()
+        K, dK = acosker(theta, x_m, xt_m, C=C, dC=dC, diag=False)
+    else:
+        x_m = xt_m if x is xtilde else x[:, mask].contiguous()
+        K, dK = K_tilde, dK_tilde
+    Kvec, dKvec = acosker(theta, x_m, x2=None, C=C, dC=dC, diag=True)
+    K_tilde_b = matmul(B, matmul(K_tilde, B), transA=True)                         # :2047
+    K_tilde_b = (K_tilde_b + K_tilde_b.T) * 0.5                                    # :2048
+    K_b = matmul(K, B)                                                             # :2049
+    dK_tilde_b = {k: matmul(B, matmul(dK_tilde[k], B), transA=True) for k in dK_tilde}   # :2061
+    dK_b = {k: matmul(dK[k], B) for k in dK}                                       # :2062
+    K_tilde_inv_b = spd_inverse(K_tilde_b)                                         # :2067 (Cholesky instead of LU)
+    KKtilde_inv_b = matmul(K_b, K_tilde_inv_b) if ntilde != nt else B              # :2068
+    f_mean, lambda_m, lambda_var, dlm, dlv = mean_f(
+        f_params=f_params, calculate_moments=True, x=x_m, K_tilde=K_tilde_b, KKtilde_inv=KKtilde_inv_b, Kvec=Kvec,
+        K=K_b, C=C, m=m_b, V=V_b, theta=theta, kernfun=acosker, dK=dK_b, dK_tilde=dK_tilde_b, dK_vec=dKvec,
+        K_tilde_inv=K_tilde_inv_b)                                                 # :2070
+    loglik, dloglik = compute_loglikelihood(r, f_mean, lambda_m, lambda_var, f_params, dlambda_m=dlm, dlambda_var=dlv)
+    KL, dKL = compute_KL_div(m_b, V_b, K_tilde_b, K_tilde_inv=K_tilde_inv_b, dK_tilde=dK_tilde_b)
+    grad = {k: -(_scalar(dloglik[k]) - _scalar(dKL[k])) for k in theta.keys()}      # :2097-2099
+    return -(_scalar(loglik) - _scalar(KL)), grad                                  # :2087-2089
+
+
+@torch.no_grad()
+def varGP(x, r, **kwargs):
+    """Variational-GP fit (EM) with the reference's call signature and ``fit_model`` schema
+    (utils.py:1568-2316): ``varGP(x, r, fit_parameters=..., xtilde=..., hyperparams_tuple=...,
+    f_params=..., [m, V, init_kernel])`` -> ``(fit_model, err_dict)``.
+
+    State is kept, as in the reference, in the eigenbasis ``B`` of K~ (``m_b``, ``V_b``).  While
+    every eigenvalue is kept and the inducing set is the training set (the regime of the
+    north-star configurations) the M-step closure is ONE call of the fused HIP unit of work
+    (``gpfit_fit_eval``) and the E-step ONE call of ``gpfit_estep`` in the original basis;
+    otherwise the same steps run in the reference's projected formulation on the GPU
+    primitives."""
+    import time
+    start_time_before_init = time.time()
+    err_dict = {'is_error': False, 'error_message': None}
+    x, r = _cu(x), _cu(r)
+    nt, nx = x.shape
+    dev = x.device
+
+    fit_parameters = copy.deepcopy(kwargs['fit_parameters'])
+    fit_parameters['min_tolerance'] = MIN_TOLERANCE
+    fit_parameters['eigval_tol'] = EIGVAL_TOL
+    ntilde = fit_parameters.get('ntilde', 100 if nt > 100 else nt)
+    maxiter = fit_parameters.get('maxiter', 50)
+    nEstep = fit_parameters.get('nEstep', 50)
+    nMstep = fit_parameters.get('nMstep', 20)
+    nFparamstep = fit_parameters.get('nFparamstep', 10)
+    display_hyper = fit_parameters.get('display_hyper', True)
+    n_px_side = fit_parameters.get('n_px_side', math.sqrt(nx))
+    if fit_parameters.get('kernfun', 'acosker') != 'acosker':
+        raise Exception('Kernel function not recognized')
+    kernfun = acosker
+
+    x_given_as_xtilde = 'xtilde' in kwargs and kwargs['xtilde'] is x
+    xtilde = _cu(kwargs['xtilde']) if 'xtilde' in kwargs else generate_xtilde(ntilde, x)
+    if ntilde != xtilde.shape[0]:
+        raise Exception('Number of inducing points does not match ntilde')
+    hyperparams_tuple = (copy.deepcopy(kwargs['hyperparams_tuple']) if 'hyperparams_tuple' in kwargs
+                         else generate_theta(x, r, n_px_side, display_hyper))
+    theta = copy.deepcopy(kwargs.get('theta', hyperparams_tuple[0]))
+    theta_lower_lims = copy.deepcopy(kwargs.get('theta_lower_lims', hyperparams_tuple[1]))
+    theta_higher_lims = copy.deepcopy(kwargs.get('theta_higher_lims', hyperparams_tuple[2]))
+    lims = (theta_lower_lims, theta_higher_lims)
+    if 'f_params' not in kwargs:
+        raise Exception('f_params not provided')
+    f_params = copy.deepcopy(kwargs['f_params'])
+    for key in f_params.keys():
+        f_params[key] = f_params[key].detach().to(TORCH_DTYPE).requires_grad_(True)
+
+    same_points = (ntilde == nt) and (x_given_as_xtilde or torch.equal(xtilde, x))
+    eigvecs = None
+
+    def build_kernels(th):
+        C_, mask_ = localker(theta=th, theta_lower_lims=theta_lower_lims, theta_higher_lims=theta_higher_lims,
+                             n_px_side=n_px_side, grad=False)
+        xt_m = xtilde[:, mask_].contiguous()
+        Kt = kernfun(th, xt_m, xt_m, C=C_, dC=None, diag=False)
+        x_m = xt_m if same_points else x[:, mask_].contiguous()
+        K_ = kernfun(th, x_m, xt_m, C=C_, dC=None, diag=False) if ntilde != nt else Kt
+        Kv = kernfun(th, x_m, x2=None, C=C_, dC=None, diag=True)
+        return C_, mask_, Kt, K_, Kv, x_m
+
+    def project(Kt, K_):
+        eigvals_, eigvecs_, ikeep_ = _eigen_stabilise(Kt)
+        B_ = eigvecs_[:, ikeep_].contiguous()
+        kept = eigvals_[ikeep_]
+        Ktb = torch.diag(kept)
+        Ktib = torch.diag_embed(1 / kept)
+        Kb = matmul(K_, B_)
+        a_ = matmul(Kb, Ktib) if ntilde != nt else B_
+        return eigvecs_, B_, Ktb, Ktib, Kb, a_
+
+    if 'init_kernel' not in kwargs:
+        C, mask, K_tilde, K, Kvec, x_m = build_kernels(theta)
+        eigvecs, B, K_tilde_b, K_tilde_inv_b, K_b, KKtilde_inv_b = project(K_tilde, K)
+    else:
+        ik = kwargs['init_kernel']
+        C, mask, K_tilde, K, Kvec = _cu(ik['C']), ik['mask'].to(dev), _cu(ik['K_tilde']), _cu(ik['K']), _cu(ik['Kvec'])
+        B, K_tilde_b, K_b, K_tilde_inv_b = _cu(ik['B']), _cu(ik['K_tilde_b']), _cu(ik['K_b']), _cu(ik['K_tilde_inv_b'])
+        KKtilde_inv_b = _cu(ik['KKtilde_inv_b']) if ntilde != nt else B
+        x_m = x[:, mask].contiguous()
+
+    m = _cu(copy.deepcopy(kwargs.get('m', torch.zeros(ntilde, dtype=TORCH_DTYPE))).detach())
+    V = _cu(copy.deepcopy(kwargs.get('V', K_tilde)).detach())
+    V_b = matmul(B, matmul(V, B), transA=True) if 'V' in kwargs else K_tilde_b
+    m_b = matmul(B, m, transA=True)
+
+    import os as _os
+    no_fast = bool(_os.environ.get("GPFIT_NO_FAST"))
+
+    def full_rank():
+        return (not no_fast) and same_points and B.shape[0] == B.shape[1]
+
+    lambda_m, lambda_var = lambda_moments(x_m, K_tilde_b, KKtilde_inv_b, Kvec, K_b, C, m_b, V_b, theta, kernfun=kernfun)
+    f_mean = mean_f_given_lambda_moments(f_params, lambda_m, lambda_var)
+    loglikelihood, _, __ = compute_loglikelihood(r, f_mean, lambda_m, lambda_var, f_params)
+    KL_div = compute_KL_div(m_b, V_b, K_tilde_b, K_tilde_inv_b, dK_tilde=None, ignore_warning=True)
+    logmarginal = loglikelihood - KL_div
+
+    loss_track = {k: torch.zeros(maxiter) for k in ('logmarginal', 'loglikelihood', 'KL')}
+    theta_track = {key: torch.zeros(maxiter) for key in theta.keys()}
+    l0key = 'lambda0' if 'lambda0' in f_params else 'loglambda0'
+    f_par_track = {'logA': torch.zeros(maxiter), l0key: torch.zeros(maxiter)}
+    values_track = {'loss_track': loss_track, 'theta_track': theta_track, 'f_par_track': f_par_track,
+                    'variation_par_track': {'V_b': (), 'm_b': ()}}
+
+    def record(it):
+        loss_track['loglikelihood'][it] = _scalar(loglikelihood)
+        loss_track['KL'][it] = _scalar(KL_div)
+        loss_track['logmarginal'][it] = _scalar(loglikelihood) - _scalar(KL_div)
+        for key in theta.keys():
+            theta_track[key][it] = _scalar(theta[key])
+        f_par_track['logA'][it] = _scalar(f_params['logA'])
+        f_par_track[l0key][it] = _scalar(f_params[l0key])
+        values_track['variation_par_track']['V_b'] += (V_b.clone(),)
+        values_track['variation_par_track']['m_b'] += (m_b.clone(),)
+
+    times = {'estep': 0.0, 'fparams': 0.0, 'mstep': 0.0, 'kernels': 0.0, 'loss': 0.0}
+    start_time_loop = time.time()
+    iteration = 0
+    try:
+        record(0)
+        print(f'Initial Loss: {-(_scalar(loglikelihood) - _scalar(KL_div)):.4f}')
+        for iteration in range(1, maxiter):
+            t0 = time.time()
+            if nMstep > 0 and iteration > 1:
+                # kernels at the theta of the last M-step, new eigenbasis, (m_b, V_b) re-projected
+                C, mask, K_tilde, K, Kvec, x_m = build_kernels(theta)                       # utils.py:1803-1806
+                B_old = B
+                eigvecs, B, K_tilde_b, K_tilde_inv_b, K_b, KKtilde_inv_b = project(K_tilde, K)   # :1808-1818
+                BtB = matmul(B, B_old, transA=True)
+                V_b = matmul(BtB, matmul(V_b, BtB, transB=True))                           # :1833
+                m_b = matmul(BtB, m_b)                                                     # :1840
+            times['kernels'] += time.time() - t0
+
+            t0 = time.time()
+            if nEstep > 0:
+                for i_estep in range(nEstep):
+                    if i_estep == 0 and nMstep > 0:
+                        lambda_m, lambda_var = lambda_moments(x_m, K_tilde_b, KKtilde_inv_b, Kvec, K_b, C, m_b, V_b,
+                                                              theta, kernfun=kernfun)         # :1871
+                        f_params['lambda0'] = lambda0_given_logA(f_params['logA'], r, lambda_m, lambda_var)  # :1874
+                    f_mean = mean_f_given_lambda_moments(f_params, lambda_m, lambda_var)        # :1877
+                    if full_rank():
+                        # fused Newton update in the original basis, then back to the eigenbasis
+                        m_orig = matmul(B, m_b)
+                        m_new = torch.empty(nt, dtype=TORCH_DTYPE, device=dev)
+                        V_new = torch.empty((nt, nt), dtype=TORCH_DTYPE, device=dev)
+                        eng = get_engine(nt, 1)
+                        rc = _lib.load().gpfit_estep(eng._ctx, _stream(), K_tilde.data_ptr(), K_tilde.stride(0), nt,
+                                                     r.data_ptr(), m_orig.data_ptr(), f_mean.data_ptr(),
+                                                     _scalar(f_params['logA']), m_new.data_ptr(), V_new.data_ptr(),
+                                                     V_new.stride(0))
+                        if rc != 0:
+                            raise torch.linalg.LinAlgError(f"Estep: {_lib.last_error()} (rc={rc})")
+                        m_b = matmul(B, m_new, transA=True)
+                        V_b = matmul(B, matmul(V_new, B), transA=True)
+                        V_b = (V_b + V_b.T) / 2
+                    else:
+                        m_b, V_b = Estep(r=r, KKtilde_inv=KKtilde_inv_b, m=m_b, f_params=f_params, f_mean=f_mean,
+                                         K_tilde=K_tilde_b, K_tilde_inv=K_tilde_inv_b, update_V_inv=False, alpha=1)  # :1880
+                    f_mean, lambda_m, lambda_var = mean_f(f_params=f_params, calculate_moments=True, x=x_m,
+                                                          K_tilde=K_tilde_b, KKtilde_inv=KKtilde_inv_b, Kvec=Kvec, K=K_b,
+                                                          C=C, m=m_b, V=V_b, theta=theta, kernfun=kernfun)   # :1884
+                    tf = time.time()
+                    f_params['lambda0'] = lambda0_given_logA(f_params['logA'], r, lambda_m, lambda_var)      # :1892
+                    opt_f = torch.optim.LBFGS([f_params['logA']], lr=0.1, max_iter=nFparamstep, tolerance_change=1.e-9,
+                                              tolerance_grad=1.e-7, history_size=nFparamstep,
+                                              line_search_fn='strong_wolfe')                                # :1897
+                    calls = [0]
+
+                    def closure_f_params():
+                        nonlocal f_mean
+                        calls[0] += 1
+                        opt_f.zero_grad()
+                        # one fused pass: f, loglik, d/dlogA with the current lambda0, and the new closed-form lambda0
+                        f_mean, out = _fparam_eval(lambda_m, lambda_var, r, f_params['logA'], False,
+                                                   _scalar(_lambda0_of(f_params)))
+                        f_params['logA'].grad = torch.tensor(-out[2], dtype=TORCH_DTYPE)                     # :1913
+                        f_params['lambda0'] = torch.tensor(out[6], dtype=TORCH_DTYPE)                        # :1916
+                        if not math.isfinite(out[3]):
+                            raise ValueError(f'Nan in f_mean during f param update in Estep, closure has been called '
+                                             f'{calls[0]} times in estep {i_estep} iteration.')              # :1923
+                        return torch.tensor(-out[1], dtype=TORCH_DTYPE)                                      # :1930
+                    opt_f.step(closure_f_params)                                                            # :1932
+                    f_params['lambda0'] = lambda0_given_logA(f_params['logA'], r, lambda_m, lambda_var)      # :1934
+                    times['fparams'] += time.time() - tf
+            else:
+                print('No E-step')
+            times['estep'] += time.time() - t0
+
+            t0 = time.time()
+            f_mean = mean_f_given_lambda_moments(f_params, lambda_m, lambda_var)                            # :1958
+            loglikelihood, _, __ = compute_loglikelihood(r, f_mean, lambda_m, lambda_var, f_params)
+            KL_div = compute_KL_div(m_b, V_b, K_tilde_b, K_tilde_inv_b, dK_tilde=None, ignore_warning=True)
+            logmarginal = loglikelihood - KL_div
+            times['loss'] += time.time() - t0
+            record(iteration)
+            print(f'Loss iter {iteration}: {-(_scalar(loglikelihood) - _scalar(KL_div)):.4f}')
+
+            t0 = time.time()
+            if nMstep > 0 and iteration < maxiter - 1:
+                opt_h = torch.optim.LBFGS(theta.values(), lr=0.1, max_iter=nMstep, line_search_fn='strong_wolfe',
+                                          tolerance_change=1.e-9, tolerance_grad=1.e-7, history_size=100)     # :2013
+                fast = full_rank()
+                if fast:
+                    # (m, V) are fixed during the M-step: go to the original basis once
+                    m_orig = matmul(B, m_b)
+                    V_orig = matmul(B, matmul(V_b, B, transB=True))
+                    V_orig = (V_orig + V_orig.T) * 0.5
+                mcalls = [0]
+
+                def closure_hyperparams():
+                    mcalls[0] += 1
+                    opt_h.zero_grad()
+                    outside = False
+                    for key, value in theta.items():                                                       # :2022-2028
+                        if not (theta_lower_lims[key] <= _scalar(value) <= theta_higher_lims[key]):
+                            outside = True
+                            print(f"{key} = {_scalar(value):.4f} is not within the limits of {theta_lower_lims[key]} and "
+                                  f"{theta_higher_lims[key]}, returning inifinite loss in closure call {mcalls[0]}")
+                            if theta[key].requires_grad:
+                                theta[key].grad = torch.tensor(float('inf'))
+                    if outside:
+                        return torch.tensor(float('inf'))
+                    if fast:
+                        e = get_engine(nt, nx, nx)
+                        res = e.fit_eval(theta, theta_lower_lims, theta_higher_lims, n_px_side, x, r, m_orig, V_orig,
+                                         _scalar(f_params['logA']), _scalar(_lambda0_of(f_params)), want_grad=True,
+                                         want_vectors=False)
+                        loss, grad = res['loss'], res['grad']
+                    else:
+                        loss, grad = _closure_general(theta, lims, n_px_side, x, xtilde, r, B, m_b, V_b, f_params,
+                                                      ntilde, nt)
+                    for key in theta.keys():
+                        if theta[key].requires_grad:
+                            theta[key].grad = torch.tensor(grad[key], dtype=TORCH_DTYPE)                       # :2098-2099
+                    return torch.tensor(loss, dtype=TORCH_DTYPE)
+
+                opt_h.step(closure_hyperparams)                                                             # :2114
+            elif iteration < maxiter - 1:
+                print(' No M-step')
+            times['mstep'] += time.time() - t0
+
+    except (KeyboardInterrupt, Exception) as e:  # utils.py:2127-2189: roll back to the last tracked state
+        print(f' ===================  Error During iteration: {iteration} =================== \n')
+        fit_parameters['maxiter'] = iteration
+        err_dict['is_error'] = True
+        err_dict['error'] = e
+        err_dict['error_message'] = repr(e)
+        if iteration > 1:
+            theta = {k: theta_track[k][iteration - 1].to(TORCH_DTYPE) for k in theta.keys()}
+            f_params['logA'] = f_par_track['logA'][iteration - 1].to(TORCH_DTYPE)
+            f_params[l0key] = f_par_track[l0key][iteration - 1].to(TORCH_DTYPE)
+            V_b = values_track['variation_par_track']['V_b'][iteration - 1]
+            m_b = values_track['variation_par_track']['m_b'][iteration - 1]
+            C, mask, K_tilde, K, Kvec, x_m = build_kernels(theta)                                           # :2196-2208
+            eigvecs, B, K_tilde_b, K_tilde_inv_b, K_b, KKtilde_inv_b = project(K_tilde, K)
+            f_mean, lambda_m, lambda_var = mean_f(f_params=f_params, calculate_moments=True, x=x_m, K_tilde=K_tilde_b,
+                                                  KKtilde_inv=KKtilde_inv_b, Kvec=Kvec, K=K_b, C=C, m=m_b, V=V_b,
+                                                  theta=theta, kernfun=kernfun)
+            loglikelihood = compute_loglikelihood(r, f_mean, lambda_m, lambda_var, f_params)[0]
+            KL_div = compute_KL_div(m_b, V_b, K_tilde_b, K_tilde_inv_b, dK_tilde=None)
+            logmarginal = loglikelihood - KL_div
+            last = fit_parameters['maxiter'] - 1
+            loss_track['loglikelihood'][last] = _scalar(loglikelihood)
+            loss_track['KL'][last] = _scalar(KL_div)
+            loss_track['logmarginal'][last] = _scalar(logmarginal)
+
+    final_kernel = {'C': C, 'mask': mask, 'K_tilde': K_tilde, 'K': K, 'Kvec': Kvec, 'eigvecs': eigvecs}
+    if not is_simmetric(V_b, 'V_b'):
+        print('Final V_b is not simmetric, maximum difference: ', torch.max(torch.abs(V_b - V_b.T)))
+        V_b = (V_b + V_b.T) / 2
+    if not is_posdef(V_b, 'V_b'):
+        print('Final V_b is not posdef, this should not be possible if you are skipping the last M-step')
+        V_b = V_b + torch.eye(V_b.shape[0], dtype=TORCH_DTYPE, device=V_b.device) * EIGVAL_TOL
+
+    print(f'\nTime spent for E-steps:       {times["estep"]:.3f}s,')
+    print(f'Time spent for f params:      {times["fparams"]:.3f}s')
+    print(f'Time spent for m / V update:  {times["estep"] - times["fparams"]:.3f}s')
+    print(f'Time spent for M-steps:       {times["mstep"]:.3f}s')
+    print(f'Time spent for All-steps:     {times["estep"] + times["mstep"]:.3f}s')
+    print(f'Time spent computing Kernels: {times["kernels"]:.3f}s')
+    print(f'Time spent computing Loss:    {times["loss"]:.3f}s')
+    print(f'\nTime total after init:        {time.time() - start_time_loop:.3f}s')
+    print(f'Time total before init:       {time.time() - start_time_before_init:.3f}s')
+    print(f'Final Loss: {-_scalar(logmarginal):.4f}')
+
+    nkeep = fit_parameters['maxiter']
+    for key in values_track.keys():
+        for sub in values_track[key].keys():
+            values_track[key][sub] = values_track[key][sub][:nkeep]
+
+    fit_model = {
+        'fit_parameters': fit_parameters, 'final_kernel': final_kernel, 'err_dict': err_dict, 'xtilde': xtilde,
+        'hyperparams_tuple': (theta, theta_lower_lims, theta_higher_lims), 'f_params': f_params, 'm_b': m_b,
+        'V_b': V_b, 'C': C, 'mask': mask, 'K_tilde_b': K_tilde_b, 'K_tilde_inv_b': K_tilde_inv_b, 'K_b': K_b,
+        'Kvec': Kvec, 'B': B, 'values_track': values_track,
+    }
+    return fit_model, err_dict
+
+
+@torch.no_grad()
+def test(X_test, R_test, xtilde, X_train=None, at_iteration=None, **kwargs):
+    """Predict the firing rate of one cell on test images from a ``fit_model`` (utils.py:326-412):
+    ``test(X_test, R_test, X_train=X, at_iteration=None, **fit_model)``.  X_test is
+    [n_images, n_px, n_px, 1]; all images go through ``lambda_moments_star`` in one batch."""
+    fp = kwargs['fit_parameters']
+    maxiter, nEstep, nMstep = fp.get('maxiter', 0), fp.get('nEstep', 0), fp.get('nMstep', 0)
+    cellid, n_px_side = fp.get('cellid'), fp.get('n_px_side')
+    mask, C = kwargs.get('mask'), kwargs.get('C')
+    theta, theta_lower_lims, theta_higher_lims = kwargs.get('hyperparams_tuple')
+    m, V, B = kwargs.get('m_b'), kwargs.get('V_b'), kwargs.get('B')
+    K_tilde, K_tilde_inv = kwargs.get('K_tilde_b'), kwargs.get('K_tilde_inv_b')
+    f_params = kwargs.get('f_params')
+    xtilde = _cu(xtilde)
+    A = math.exp(_scalar(f_params['logA']))
+    lambda0 = _scalar(_lambda0_of(f_params))
+
+    if at_iteration is not None and X_train is not None:                                   # utils.py:358-386
+        vt = kwargs['values_track']
+        theta = {key: val[at_iteration] for key, val in vt['theta_track'].items()}
+        m = vt['variation_par_track']['m_b'][at_iteration]
+        V = vt['variation_par_track']['V_b'][at_iteration]
+        A = math.exp(_scalar(vt['f_par_track']['logA'][at_iteration]))
+        lambda0 = (_scalar(vt['f_par_track']['lambda0'][at_iteration]) if 'lambda0' in vt['f_par_track']
+                   else math.exp(_scalar(vt['f_par_track']['loglambda0'][at_iteration])))
+        C, mask = localker(theta=theta, theta_higher_lims=theta_higher_lims, theta_lower_lims=theta_lower_lims,
+                           n_px_side=n_px_side, grad=False)
+        xt_m = xtilde[:, mask].contiguous()
+        Kt = acosker(theta, xt_m, xt_m, C=C, diag=False)
+        eigvals, eigvecs, ikeep = _eigen_stabilise(Kt)
+        B = eigvecs[:, ikeep].contiguous()
+        K_tilde = torch.diag(eigvals[ikeep])
+        K_tilde_inv = torch.diag_embed(1 / eigvals[ikeep])
+
+    X_test = _cu(X_test)
+    n_img = X_test.shape[0]
+    xstar = X_test.reshape(n_img, -1)                                                      # utils.py:389-390
+    mask = mask.to(xstar.device)
+    mu_star, sigma_star2 = lambda_moments_star(xstar[:, mask].contiguous(), xtilde[:, mask].contiguous(), C, theta,
+                                               K_tilde, K_tilde_inv, m, V, B, 'acosker')   # :393
+    R_predicted = torch.exp(A * mu_star + 0.5 * A * A * sigma_star2 + lambda0)              # :395
+    R_test = _cu(R_test)
+    r2, sigma_r2 = explained_variance(R_test[:, :, cellid], R_predicted, sigma=True)        # :400
+    print(f"\n\n Pietro's model: R2 = {float(r2):.2f} ± {float(sigma_r2):.2f} Cell: {cellid} maxiter = {maxiter}, "
+          f"nEstep = {nEstep}, nMstep = {nMstep} \n")
+    return R_test[:, :, cellid], R_predicted, r2, sigma_r2

@@ -103,6 +103,32 @@ int gpfit_fit_eval(gpfit_ctx* ctx, void* stream, const double* theta, const doub
                    double lambda0, int want_grad, double* out_host, double* lam_m, double* lam_var,
                    double* f);
 
+/* Cholesky factorisation A = L L^T of a symmetric positive definite n x n matrix (lower
+ * triangle read) by the recursive MFMA algorithm; replaces torch.linalg.cholesky in log_det
+ * (utils.py:1275) and, through L^-1, the LU torch.linalg.solve(., I) of the closure
+ * (utils.py:2067).  L / Linv (device, may be NULL) receive the factor and its inverse with the
+ * strict upper part zeroed; *logdet_host = 2 sum log L_ii (utils.py:1278).  Synchronises.
+ * Returns 0, or the LAPACK info (1-based index of the first non-positive pivot). */
+int gpfit_potrf(gpfit_ctx* ctx, void* stream, const double* A, int64_t lda, int64_t n, double* L, int64_t ldl,
+                double* Linv, int64_t ldi, double* logdet_host, int* info_host);
+
+/* E-step Newton update of q(lambda~) = N(m, V) (Estep, alpha = 1 branch, utils.py:1420-1439) in
+ * the original basis (a = I): with s = A sqrt(f), M = I + S K~ S = L_M L_M^T, T = L_M^-1 S K~:
+ *   V_new = K~ - T^T T,  m_new = V_new (A^2 f o m + A (r - f)).
+ * K~[N][ldk] symmetric (full), r, m, f [N] -> m_new [N], V_new[N][ldv] (full, symmetric).
+ * Synchronises; returns LAPACK info if M is not positive definite. */
+int gpfit_estep(gpfit_ctx* ctx, void* stream, const double* K, int64_t ldk, int64_t N, const double* r,
+                const double* m, const double* f, double logA, double* m_new, double* V_new, int64_t ldv);
+
+/* One pass over the training points for the firing-rate parameters (mean_f_given_lambda_moments
+ * utils.py:1126-1141, lambda0_given_logA :1215-1229, compute_loglikelihood with
+ * compute_grad_for_f_params :1243-1255).  out_host[7]: lambda0 used (closed form if requested,
+ * else lambda0_in), loglik, d loglik / d logA, sum f, sum r, r.lam_m, closed-form lambda0.
+ * f_out (device [N]) may be NULL. */
+int gpfit_fparam_eval(gpfit_ctx* ctx, void* stream, const double* lam_m, const double* lam_var,
+                      const double* r, int64_t N, double logA, int closed_form_lambda0, double lambda0_in,
+                      double* f_out, double* out_host);
+
 /* Per-launch HIP-event timing of the dominant kernels during gpfit_fit_eval (bench.py's
  * roofline leg; adds two event records per launch, so leave it off when timing throughput).
  * out8: 0 sum of dgemm launch durations [ms], 1 flops those launches executed, 2 #launches,
