@@ -139,7 +139,7 @@ int gpfit_get_profile(gpfit_ctx* ctx, double* out8);
 double gpfit_last_enqueue_ms(gpfit_ctx* ctx);
 
 /* Roofline probes (no reference counterpart): back-to-back v_mfma_f64_16x16x4_f64 issue
- * (flops = blocks*4 waves*iters*8*2048) and a 16-byte-per-lane stream copy. */
+ * (flops = blocks*4 waves*iters*16*2048) and a 16-byte-per-lane stream copy. */
 int gpfit_probe_mfma_f64(void* stream, double* scratch, int blocks, int iters);
 int gpfit_probe_stream_copy(void* stream, const double* in, double* out, int64_t n_doubles);
 

@@ -67,3 +67,29 @@ def test_missing_gpu_fails_loudly():
         pytest.skip("GPU present")
     with pytest.raises(_lib.GpfitError):
         GPFitEngine(64, 16)
+
+
+def test_dropin_module_imports_and_refuses_to_run_without_gpu():
+    """The host module must import anywhere (so build() can check it) but every compute entry
+    point fails loudly without a GPU -- there is no CPU fallback on the product path."""
+    import torch
+    from gaussian_processes_amd import utils as gp
+    for name in ("localker", "acosker", "lambda_moments", "mean_f_given_lambda_moments", "mean_f", "lambda0_given_logA",
+                 "compute_loglikelihood", "log_det", "compute_KL_div", "Estep", "lambda_moments_star", "varGP", "test",
+                 "generate_theta", "generate_xtilde", "explained_variance", "is_posdef", "is_simmetric", "safe_log"):
+        assert callable(getattr(gp, name)), name
+    assert gp.EIGVAL_TOL == 1e-4 and gp.MIN_TOLERANCE == 1e-11 and gp.TORCH_DTYPE == torch.float64
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    lo, up = syn.limits()
+    with pytest.raises(_lib.GpfitError):
+        gp.localker(syn.theta0(), up, lo, 8)
+
+
+def test_product_package_never_imports_the_oracle():
+    """oracle/ is test infrastructure: no file of the product package may import it."""
+    import glob
+    pkg = os.path.join(ROOT, "gaussian_processes_amd")
+    for f in glob.glob(os.path.join(pkg, "**", "*.py"), recursive=True):
+        src = open(f).read()
+        assert "import oracle" not in src and "from oracle" not in src, f

@@ -202,3 +202,28 @@ def test_headline_gradient_matches_finite_difference(dev, headline):
     fd = (lp - lm) / (2 * h)
     an = sum(base["grad"][k] * direction[k] for k in KEYS)
     assert abs(fd - an) <= 2e-5 * abs(an), (fd, an)
+
+
+def test_sharded_cells_driver_on_one_gpu(dev):
+    """multi.run_sharded with the GPU evaluator (world size 1): four independent cells that share
+    X, each checked against the oracle -- the per-rank body of BASELINE config[3]."""
+    from gaussian_processes_amd import multi
+    N, d, cells = 256, 64, 4
+    grid = syn.grid_for(d)
+    X = T(syn.stimuli(N, d))
+    Xd = X.to(dev)
+    eng = engine(N, d)
+    expected = []
+
+    def eval_cell(cell):
+        _, _, r, m, V, th1 = synthetic_case(N, d, cell=cell)
+        loss, grad = orc.mstep_closure_cholesky(th1, LOWER, UPPER, grid, X, r, m, V, LOGA, LAM0)
+        expected.append([loss] + [grad[k] for k in KEYS])
+        res = eng.fit_eval(th1, LOWER, UPPER, grid, Xd, r.to(dev), m.to(dev), V.to(dev), LOGA, LAM0)
+        return [res["loss"]] + [res["grad"][k] for k in KEYS]
+
+    table = multi.run_sharded(cells, eval_cell, dev).cpu().numpy()
+    exp = np.array(expected)
+    assert table.shape == (cells, 7)
+    assert np.abs(table[:, 0] - exp[:, 0]).max() <= 1e-9 * np.abs(exp[:, 0]).max()
+    assert np.abs(table[:, 1:] - exp[:, 1:]).max() <= 1e-6 * np.abs(exp[:, 1:]).max()
