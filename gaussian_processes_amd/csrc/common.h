@@ -55,9 +55,14 @@ struct GemmArgs {
   int split_k;               // >1: partial products written to C + z*sC (beta ignored)
   int tile;                  // 0 = choose (128 / 64 / 32), else forced block tile
   int reverse;               // tile walk: bit 0 backwards, bit 1 column-major (dense output)
+  int workspace;             // stream-K partial-tile workspace to use (0 main stream, 1 aux stream)
+  int tile_limit;            // >0: launch only the first tile_limit tiles of the walk (stream-K head)
 };
 int launch_gemm(const GemmArgs& a, hipStream_t s);
-int gemm_pick_tile(const GemmArgs& a);  // block tile the launcher will use (128 / 64 / 32)
+int gemm_pick_tile(const GemmArgs& a);
+// stream-K schedule for large 128-tile launches (gemm_streamk.hip): 0 issued, 1 not applicable
+int launch_gemm_streamk(const GemmArgs& a, hipStream_t s);
+int launch_gemm_plain(const GemmArgs& a, hipStream_t s);  // data-parallel launch, no stream-K  // block tile the launcher will use (128 / 64 / 32)
 
 // Arc-cosine Gram matrix from the k-major, zero-padded operands XCt[Kd][ld1], Xt[Kd][ld2]:
 //   G = XCt^T Xt + s0^2 ; c = clip(G/(q1 q2 + 1e-7)) ; K = q1 q2 J(c)

@@ -40,6 +40,8 @@ struct gpfit_ctx {
 
   // cached state of the last upload / evaluation (used by estep / predict entry points)
   int cur_n = 0, cur_np = 0, cur_d = 0, cur_dp = 0;
+  bool lv_valid = false;  // LVbuf / scal[40] hold the factor and log-det of the last V
+  int lv_n = 0;
 };
 
 namespace gpfit {
@@ -61,6 +63,7 @@ struct CholBufs {
   double* Tmp;  // scratch, same shape
   int64_t ld;
   int* info;
+  int ws = 0;   // stream-K workspace id (1 for the factorisation running on the aux stream)
 };
 // Recursive blocked Cholesky of the n x n diagonal block at offset r0 (n a multiple of 128),
 // built entirely from the MFMA GEMM and the 128 x 128 leaf.  With need_inv the full inverse of

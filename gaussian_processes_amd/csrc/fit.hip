@@ -90,7 +90,7 @@ double gemm_flops(const GemmArgs& g) {
 // ------------------------------------------------------------------ GEMM convenience
 static int gemm(hipStream_t s, int a_kmajor, int b_kmajor, int M, int N, int K, double alpha, const double* A,
                 int64_t lda, const double* B, int64_t ldb, double beta, double* C, int64_t ldc, int out_lower,
-                int a_tri, int b_tri, int reverse = 0) {
+                int a_tri, int b_tri, int reverse = 0, int ws = 0) {
   GemmArgs g{};
   g.A = A; g.B = B; g.C = C;
   g.lda = lda; g.ldb = ldb; g.ldc = ldc;
@@ -98,7 +98,7 @@ static int gemm(hipStream_t s, int a_kmajor, int b_kmajor, int M, int N, int K, 
   g.alpha = alpha; g.beta = beta;
   g.a_kmajor = a_kmajor; g.b_kmajor = b_kmajor;
   g.out_lower = out_lower; g.a_tri = a_tri; g.b_tri = b_tri;
-  g.batch = 1; g.split_k = 1; g.reverse = reverse;
+  g.batch = 1; g.split_k = 1; g.reverse = reverse; g.workspace = ws;
   ProfScope ps(s, g_prof ? gemm_flops(g) : 0.0, 0);
   return launch_gemm(g, s);
 }
@@ -122,14 +122,14 @@ int potrf_rec(const CholBufs& B, int r0, int n, bool need_inv, hipStream_t s) {
   const int r1 = r0 + n1;
   GP_TRY(potrf_rec(B, r0, n1, true, s));
   // L21 = A21 * L11^-T       (trsm as a GEMM against the explicit inverse; op(B) = Li11^T is upper)
-  GP_TRY(gemm(s, 0, 0, n2, n1, n1, 1.0, at(B.A, r1, r0), ld, at(B.Li, r0, r0), ld, 0.0, at(B.L, r1, r0), ld, 0, 0, 2, /*walk=*/3));
+  GP_TRY(gemm(s, 0, 0, n2, n1, n1, 1.0, at(B.A, r1, r0), ld, at(B.Li, r0, r0), ld, 0.0, at(B.L, r1, r0), ld, 0, 0, 2, /*walk=*/3, B.ws));
   // A22 -= L21 L21^T          (syrk, lower tiles only)
-  GP_TRY(gemm(s, 0, 0, n2, n2, n1, -1.0, at(B.L, r1, r0), ld, at(B.L, r1, r0), ld, 1.0, at(B.A, r1, r1), ld, 1, 0, 0));
+  GP_TRY(gemm(s, 0, 0, n2, n2, n1, -1.0, at(B.L, r1, r0), ld, at(B.L, r1, r0), ld, 1.0, at(B.A, r1, r1), ld, 1, 0, 0, 0, B.ws));
   GP_TRY(potrf_rec(B, r1, n2, need_inv, s));
   if (need_inv) {
     // Li21 = -Li22 * (L21 * Li11)
-    GP_TRY(gemm(s, 0, 1, n2, n1, n1, 1.0, at(B.L, r1, r0), ld, at(B.Li, r0, r0), ld, 0.0, at(B.Tmp, r1, r0), ld, 0, 0, 1, /*walk=*/2));
-    GP_TRY(gemm(s, 0, 1, n2, n1, n2, -1.0, at(B.Li, r1, r1), ld, at(B.Tmp, r1, r0), ld, 0.0, at(B.Li, r1, r0), ld, 0, 1, 0, /*walk=*/1));
+    GP_TRY(gemm(s, 0, 1, n2, n1, n1, 1.0, at(B.L, r1, r0), ld, at(B.Li, r0, r0), ld, 0.0, at(B.Tmp, r1, r0), ld, 0, 0, 1, /*walk=*/2, B.ws));
+    GP_TRY(gemm(s, 0, 1, n2, n1, n2, -1.0, at(B.Li, r1, r1), ld, at(B.Tmp, r1, r0), ld, 0.0, at(B.Li, r1, r0), ld, 0, 1, 0, /*walk=*/1, B.ws));
   }
   return 0;
 }
@@ -331,13 +331,20 @@ int gpfit_fit_eval(gpfit_ctx* c, void* stream, const double* theta, const double
   GP_HIP(hipMemsetAsync(c->mpad, 0, (size_t)np * sizeof(double), s));
   GP_HIP(hipMemcpyAsync(c->mpad, m, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, s));
 
-  // ---- aux stream: Cholesky of V (only log|V| and L_V are needed; no full inverse)
+  // ---- aux stream: Cholesky of V (only log|V| and L_V are needed; no full inverse).
+  // Opt-in reuse (flag bit 1 of want_grad): the caller promises V is the matrix of the previous
+  // call on this context (V is constant during an M-step, utils.py:2016-2114), so L_V and
+  // log|V| are kept.  bench.py never sets it: the unit of work includes this factorisation.
+  const bool reuse_V = (want_grad & 2) && c->lv_valid && c->lv_n == n;
+  want_grad &= 1;
   GP_HIP(hipEventRecord(c->ev_fork, s));
   GP_HIP(hipStreamWaitEvent(sa, c->ev_fork, 0));
-  GP_TRY(launch_pack_lower(V, ldv, n, c->Vbuf, ld, np, sa));
-  {
-    CholBufs bv{c->Vbuf, c->LVbuf, c->LiVbuf, c->TmpV, ld, c->info + 1};
+  if (!reuse_V) {
+    c->lv_valid = false;
+    GP_TRY(launch_pack_lower(V, ldv, n, c->Vbuf, ld, np, sa));
+    CholBufs bv{c->Vbuf, c->LVbuf, c->LiVbuf, c->TmpV, ld, c->info + 1, 1};
     GP_TRY(potrf_rec(bv, 0, np, false, sa));
+    GP_TRY(launch_logdet(c->LVbuf, ld, n, c->scal + 40, sa));
   }
   GP_HIP(hipEventRecord(c->ev_join, sa));
 
@@ -367,7 +374,6 @@ int gpfit_fit_eval(gpfit_ctx* c, void* stream, const double* theta, const double
 
   // ---- join: everything that needs both factors
   GP_HIP(hipStreamWaitEvent(s, c->ev_join, 0));
-  GP_TRY(launch_logdet(c->LVbuf, ld, n, c->scal + 4, s));
   // T = L^-1 L_V (lower x lower -> lower);  tr(K~^-1 V) = ||T||_F^2
   GP_TRY(gemm(s, 0, 1, np, np, np, 1.0, c->Libuf, ld, c->LVbuf, ld, 0.0, c->Tbuf, ld, 1, 1, 1, /*reverse=*/1));
   GP_TRY(launch_frob_lower(c->Tbuf, ld, np, c->scal + 5, c->frob_part, s));
@@ -381,7 +387,7 @@ int gpfit_fit_eval(gpfit_ctx* c, void* stream, const double* theta, const double
     GP_TRY(launch_add_diag(c->Wbuf, ld, np, 1.0, s));
     GP_TRY(launch_symmetrize(c->Wbuf, ld, np, s));
     GP_TRY(gemm(s, 1, 1, np, np, np, 1.0, c->Wbuf, ld, c->Libuf, ld, 0.0, c->Zbuf, ld, 0, 0, 1, /*walk=*/2));
-    GP_TRY(gemm(s, 1, 1, np, np, np, 0.5, c->Libuf, ld, c->Zbuf, ld, 0.0, c->Wbuf, ld, 1, 2, 0));
+    GP_TRY(gemm(s, 1, 1, np, np, np, 0.5, c->Libuf, ld, c->Zbuf, ld, 0.0, c->Wbuf, ld, 1, 2, 0, /*walk=*/1));
     GP_TRY(launch_adjoint(c->Wbuf, c->Cos, ld, c->bv, c->q, n, np, c->Abuf, c->upart, c->vpart, c->sumA_part, s));
     const int t64 = np / 64;
     GP_TRY(launch_adjoint_reduce(c->upart, c->vpart, c->sumA_part, t64, t64 * (t64 + 1) / 2, c->q, c->wl, n, np,
@@ -417,7 +423,8 @@ int gpfit_fit_eval(gpfit_ctx* c, void* stream, const double* theta, const double
   const double loglik = A * sc[0] + lambda0 * sc[1] - sc[2];                   // utils.py:1243
   // the identity padding of both factors contributes exactly (np - n) to ||L^-1 L_V||_F^2
   const double trKinvV = sc[5] - (double)(np - n);
-  const double KL = -0.5 * sc[4] + 0.5 * sc[3] + 0.5 * sc[6] + 0.5 * trKinvV;  // utils.py:1326
+  const double logdetV = sc[40];
+  const double KL = -0.5 * logdetV + 0.5 * sc[3] + 0.5 * sc[6] + 0.5 * trKinvV;  // utils.py:1326
   out_host[0] = -(loglik - KL);                                                // utils.py:2087-2089
   out_host[1] = loglik;
   out_host[2] = KL;
@@ -434,7 +441,7 @@ int gpfit_fit_eval(gpfit_ctx* c, void* stream, const double* theta, const double
     for (int i = 0; i < 6; ++i) out_host[3 + i] = 0.0;
   }
   out_host[9] = sc[3];
-  out_host[10] = sc[4];
+  out_host[10] = logdetV;
   out_host[11] = trKinvV;
   out_host[12] = sc[6];
   out_host[13] = (double)d;
@@ -448,6 +455,8 @@ int gpfit_fit_eval(gpfit_ctx* c, void* stream, const double* theta, const double
     set_error("Cholesky of V failed: non-positive pivot");
     return c->info_host[1];
   }
+  c->lv_valid = true;
+  c->lv_n = n;
   return 0;
 }
 

@@ -2,6 +2,8 @@
 // batching and split-K.  See common.h for the argument contract.
 #include "gemm_core.h"
 
+#include <algorithm>
+
 namespace gpfit {
 
 template <bool A_KMAJOR, bool B_KMAJOR, bool EDGE, int T>
@@ -90,7 +92,7 @@ static void launch_T(const GemmArgs& p, hipStream_t s) {
   const int tm = (p.M + T - 1) / T, tn = (p.N + T - 1) / T;
   const int tiles = p.out_lower ? lower_tile_count((p.M + TILE - 1) / TILE, TILE / T) : tm * tn;
   const bool edge = (p.M % T) || (p.N % T) || (p.out_lower && (p.M % TILE));
-  dim3 grid(tiles, p.batch, p.split_k > 1 ? p.split_k : 1);
+  dim3 grid(p.tile_limit > 0 ? std::min(p.tile_limit, tiles) : tiles, p.batch, p.split_k > 1 ? p.split_k : 1);
   dim3 block(GEMM_THREADS);
 #define GP_LAUNCH(AK, BK, ED) \
   hipLaunchKernelGGL((dgemm_mfma_kernel<AK, BK, ED, T>), grid, block, 0, s, p, tn, tiles)
@@ -109,6 +111,15 @@ static void launch_T(const GemmArgs& p, hipStream_t s) {
 }
 
 int launch_gemm(const GemmArgs& a, hipStream_t s) {
+  if (a.M <= 0 || a.N <= 0) return 0;
+  if (a.tile_limit == 0 && gemm_pick_tile(a) == TILE && a.batch <= 1) {
+    const int rc = launch_gemm_streamk(a, s);  // large launches: balanced schedules (gemm_streamk.hip)
+    if (rc <= 0) return rc;
+  }
+  return launch_gemm_plain(a, s);
+}
+
+int launch_gemm_plain(const GemmArgs& a, hipStream_t s) {
   if (a.M <= 0 || a.N <= 0) return 0;
   // odd M/N are fine for the stores; k-major operands are then read one element past M/N,
   // which internal callers cover with zero padding (the public gpfit_dgemm insists on even).

@@ -1,0 +1,264 @@
+// Stream-K schedule for the large fp64 MFMA GEMM launches.
+//
+// The data-parallel launch (gemm.hip) gives every 128 x 128 output tile to one workgroup.  With
+// 2 workgroups per CU the chip runs 512 tiles at a time, so a 2080-tile SYRK takes 5 rounds
+// for 4.06 rounds of work, a 528-tile one 2 rounds for 1.03, and triangular operands (k range
+// proportional to the tile position) leave most CUs idle behind a few long tiles: measured
+// 51-58 TF/s against 66 for the dense 4096-tile case.
+//
+// Here the (tile, k-step) iteration space is flattened in the launch's tile-walk order and cut
+// into one equal contiguous share per resident workgroup.  A workgroup whose share starts or
+// ends inside a tile writes that tile's partial accumulator to a workspace slot (at most two
+// per workgroup); a second tiny kernel adds the partials of each split tile IN A FIXED ORDER
+// and applies alpha/beta, so results are bit-reproducible (no atomics).  The plan (tile table,
+// fix-up lists) depends only on the launch shape and is cached on the device.
+#include "gemm_core.h"
+
+#include <algorithm>
+#include <cstdlib>
+#include <map>
+#include <mutex>
+#include <tuple>
+#include <vector>
+
+namespace gpfit {
+
+struct SkTile {
+  int row0, col0, kbeg, ksteps;
+  int prefix;  // k-steps of all tiles before this one in walk order (< 2^31: 4096 tiles x 512 steps)
+};
+
+struct SkPlan {
+  SkTile* tiles = nullptr;   // device
+  int ntiles = 0;
+  int total = 0;
+  int blocks = 0;
+  int per_block = 0;
+  int* fix_tile = nullptr;   // device: split tile ids
+  int* fix_ptr = nullptr;    // device: CSR offsets into fix_slot
+  int* fix_slot = nullptr;   // device: workspace slots in accumulation order
+  int nfix = 0;
+};
+
+struct SkParams {
+  const double* A;
+  const double* B;
+  double* C;
+  int64_t lda, ldb, ldc;
+  int M, N;
+  double alpha, beta;
+  const SkTile* tiles;
+  int ntiles;
+  int total, per_block;
+  double* partial;
+};
+
+constexpr int SK_SLOTS = 512;  // resident workgroups: 256 CUs x 2 (244 VGPRs, 64 KiB LDS each)
+
+template <bool A_KMAJOR, bool B_KMAJOR>
+__global__ __launch_bounds__(GEMM_THREADS, 2) void dgemm_streamk_kernel(SkParams p) {
+  __shared__ __attribute__((aligned(16))) double smem[4 * KTILE * TILE];
+  int it = (int)blockIdx.x * p.per_block;
+  const int it_end = min(p.total, it + p.per_block);
+  if (it >= it_end) return;
+  // first tile whose range contains `it` (binary search on the prefix sums)
+  int lo = 0, hi = p.ntiles - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (p.tiles[mid].prefix <= it) lo = mid; else hi = mid - 1;
+  }
+  int t = lo, nseg = 0;
+  while (it < it_end) {
+    const SkTile tl = p.tiles[t];
+    const int tbeg = tl.prefix, tend = tbeg + tl.ksteps;
+    const int s1 = min(it_end, tend);
+    const int kb = tl.kbeg + (it - tbeg) * KTILE, ke = tl.kbeg + (s1 - tbeg) * KTILE;
+    v4d acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = v4d{0.0, 0.0, 0.0, 0.0};
+    gemm_mainloop<A_KMAJOR, B_KMAJOR, false, TILE>(p.A, p.lda, p.B, p.ldb, p.M, p.N, tl.row0, tl.col0, kb, ke,
+                                                   smem, acc);
+    if (it == tbeg && s1 == tend) {
+      double* __restrict__ C = p.C;
+      const int64_t ldc = p.ldc;
+      const double alpha = p.alpha, beta = p.beta;
+      if (beta == 0.0) {
+        for_each_acc<TILE>(acc, tl.row0, tl.col0,
+                           [&](int row, int col, double v) { C[(int64_t)row * ldc + col] = alpha * v; });
+      } else {
+        for_each_acc<TILE>(acc, tl.row0, tl.col0, [&](int row, int col, double v) {
+          double* c = C + (int64_t)row * ldc + col;
+          *c = alpha * v + beta * (*c);
+        });
+      }
+    } else {
+      double* __restrict__ P = p.partial + ((int64_t)2 * blockIdx.x + (nseg > 0 ? 1 : 0)) * (TILE * TILE);
+      for_each_acc<TILE>(acc, 0, 0, [&](int row, int col, double v) { P[row * TILE + col] = v; });
+    }
+    ++nseg;
+    it = s1;
+    ++t;
+  }
+}
+
+// C tile = alpha * (sum of its partial slots, in plan order) + beta * C
+__global__ __launch_bounds__(256) void streamk_fixup_kernel(SkParams p, const int* __restrict__ fix_tile,
+                                                            const int* __restrict__ fix_ptr,
+                                                            const int* __restrict__ fix_slot) {
+  const SkTile tl = p.tiles[fix_tile[blockIdx.x]];
+  const int s0 = fix_ptr[blockIdx.x], s1 = fix_ptr[blockIdx.x + 1];
+  for (int e = threadIdx.x; e < TILE * TILE / 2; e += blockDim.x) {
+    const int r = e >> 6, c = (e & 63) * 2;
+    v2d sum = v2d{0.0, 0.0};
+    for (int s = s0; s < s1; ++s)
+      sum += *reinterpret_cast<const v2d*>(p.partial + (int64_t)fix_slot[s] * (TILE * TILE) + r * TILE + c);
+    double* cp = p.C + (int64_t)(tl.row0 + r) * p.ldc + tl.col0 + c;
+    if (p.beta == 0.0) {
+      cp[0] = p.alpha * sum.x;
+      cp[1] = p.alpha * sum.y;
+    } else {
+      cp[0] = p.alpha * sum.x + p.beta * cp[0];
+      cp[1] = p.alpha * sum.y + p.beta * cp[1];
+    }
+  }
+}
+
+using SkKey = std::tuple<int, int, int, int, int, int, int>;
+static std::map<SkKey, SkPlan> g_plans;
+static std::mutex g_plan_mutex;
+static double* g_workspace[2] = {nullptr, nullptr};
+
+static int build_plan(const GemmArgs& a, int first, SkPlan& plan) {
+  const int tm = a.M / TILE, tn = a.N / TILE;
+  const int all_tiles = a.out_lower ? tm * (tm + 1) / 2 : tm * tn;
+  const int ntiles = all_tiles - first;
+  std::vector<SkTile> tiles;
+  tiles.reserve(ntiles);
+  long long prefix = 0;
+  for (int b = first; b < all_tiles; ++b) {
+    const int bid = (a.reverse & 1) ? (all_tiles - 1 - b) : b;
+    int ti, tj;
+    if (a.out_lower) tri_tile(bid, ti, tj);
+    else if (a.reverse & 2) { tj = bid / tm; ti = bid % tm; }
+    else { ti = bid / tn; tj = bid % tn; }
+    int kb = 0, ke = a.K;
+    if (a.a_tri == 1) ke = std::min(ke, ti * TILE + TILE);
+    if (a.a_tri == 2) kb = std::max(kb, ti * TILE);
+    if (a.b_tri == 1) kb = std::max(kb, tj * TILE);
+    if (a.b_tri == 2) ke = std::min(ke, tj * TILE + TILE);
+    const int ks = std::max(0, ke - kb) / KTILE;
+    if (ks == 0) return 1;  // empty tiles would need a beta-only pass: leave those launches to gemm.hip
+    tiles.push_back(SkTile{ti * TILE, tj * TILE, kb, ks, (int)prefix});
+    prefix += ks;
+  }
+  plan.ntiles = ntiles;
+  if (prefix >= (1LL << 31)) return 1;
+  plan.total = (int)prefix;
+  plan.blocks = (int)std::min<long long>(SK_SLOTS, prefix);
+  plan.per_block = (int)((prefix + plan.blocks - 1) / plan.blocks);
+  // replay the kernel's walk to list, per split tile, the slots in accumulation (block) order
+  std::vector<std::vector<int>> slots(ntiles);
+  int t = 0;
+  for (int b = 0; b < plan.blocks; ++b) {
+    int it = b * plan.per_block;
+    const int it_end = std::min(plan.total, it + plan.per_block);
+    if (it >= it_end) break;
+    while (tiles[t].prefix + tiles[t].ksteps <= it) ++t;
+    int tt = t, nseg = 0;
+    while (it < it_end) {
+      const int tbeg = tiles[tt].prefix, tend = tbeg + tiles[tt].ksteps;
+      const int s1 = std::min(it_end, tend);
+      if (!(it == tbeg && s1 == tend)) slots[tt].push_back(2 * b + (nseg > 0 ? 1 : 0));
+      ++nseg;
+      it = s1;
+      ++tt;
+    }
+  }
+  std::vector<int> fix_tile, fix_ptr{0}, fix_slot;
+  for (int i = 0; i < ntiles; ++i)
+    if (!slots[i].empty()) {
+      fix_tile.push_back(i);
+      fix_slot.insert(fix_slot.end(), slots[i].begin(), slots[i].end());
+      fix_ptr.push_back((int)fix_slot.size());
+    }
+  plan.nfix = (int)fix_tile.size();
+  GP_HIP(hipMalloc((void**)&plan.tiles, tiles.size() * sizeof(SkTile)));
+  GP_HIP(hipMemcpy(plan.tiles, tiles.data(), tiles.size() * sizeof(SkTile), hipMemcpyHostToDevice));
+  if (plan.nfix) {
+    GP_HIP(hipMalloc((void**)&plan.fix_tile, fix_tile.size() * sizeof(int)));
+    GP_HIP(hipMalloc((void**)&plan.fix_ptr, fix_ptr.size() * sizeof(int)));
+    GP_HIP(hipMalloc((void**)&plan.fix_slot, fix_slot.size() * sizeof(int)));
+    GP_HIP(hipMemcpy(plan.fix_tile, fix_tile.data(), fix_tile.size() * sizeof(int), hipMemcpyHostToDevice));
+    GP_HIP(hipMemcpy(plan.fix_ptr, fix_ptr.data(), fix_ptr.size() * sizeof(int), hipMemcpyHostToDevice));
+    GP_HIP(hipMemcpy(plan.fix_slot, fix_slot.data(), fix_slot.size() * sizeof(int), hipMemcpyHostToDevice));
+  }
+  return 0;
+}
+
+// Returns 0 when the launch was issued here, 1 when the caller should use the plain
+// data-parallel launch, < 0 on error.  Two uses:
+//  * operands triangular on both sides (k range of a tile ~ distance from the diagonal): pure
+//    stream-K over all tiles (+8 % on L^-1 L_V, T T^T, L^-T R);
+//  * uniform k range whose tile count leaves a short last round (2080 = 4 x 512 + 32): the full
+//    rounds stay data-parallel -- workgroups that start together walk k in lock step and share
+//    operand panels in L2, which stream-K's staggered shares give up -- and only the tail tiles
+//    are cut along k over the whole chip.
+int launch_gemm_streamk(const GemmArgs& a, hipStream_t s) {
+  static const bool disabled = getenv("GPFIT_NO_STREAMK") != nullptr;
+  if (disabled) return 1;
+  if ((a.M % TILE) || (a.N % TILE) || a.split_k > 1 || a.batch > 1 || (a.tile && a.tile != TILE)) return 1;
+  const long tm = a.M / TILE, tn = a.N / TILE;
+  const int ntiles = (int)(a.out_lower ? tm * (tm + 1) / 2 : tm * tn);
+  if (ntiles < 384 || (long)a.K < 1024) return 1;  // small launches: latency-, not balance-bound
+  int first = 0;
+  const bool both_tri = (a.a_tri != 0 && a.b_tri != 0) || (a.out_lower && a.a_tri == 2);
+  if (!both_tri) {
+    if (a.a_tri || a.b_tri) return 1;       // one-sided triangles: the heavy-first walk already balances
+    const int tail = ntiles % SK_SLOTS;
+    if (tail == 0 || tail >= 384 || ntiles < SK_SLOTS) return 1;
+    first = ntiles - tail;
+  }
+  const int ws = (a.workspace == 1) ? 1 : 0;
+  SkPlan plan;
+  {
+    std::lock_guard<std::mutex> lock(g_plan_mutex);
+    const SkKey key{a.M, a.N, a.K, a.out_lower, a.a_tri, a.b_tri, (a.reverse & 3) | (first ? 4 : 0)};
+    auto itp = g_plans.find(key);
+    if (itp == g_plans.end()) {
+      SkPlan np;
+      const int rc = build_plan(a, first, np);
+      if (rc != 0) return rc;
+      itp = g_plans.emplace(key, np).first;
+    }
+    plan = itp->second;
+    if (!g_workspace[ws]) GP_HIP(hipMalloc((void**)&g_workspace[ws], (size_t)2 * SK_SLOTS * TILE * TILE * sizeof(double)));
+  }
+  if (first > 0) {  // the full rounds, data-parallel
+    GemmArgs head = a;
+    head.tile = TILE;
+    head.tile_limit = first;
+    const int rc = launch_gemm_plain(head, s);
+    if (rc != 0) return rc;
+  }
+  SkParams p{};
+  p.A = a.A; p.B = a.B; p.C = a.C; p.lda = a.lda; p.ldb = a.ldb; p.ldc = a.ldc; p.M = a.M; p.N = a.N;
+  p.alpha = a.alpha; p.beta = a.beta; p.tiles = plan.tiles; p.ntiles = plan.ntiles; p.total = plan.total;
+  p.per_block = plan.per_block; p.partial = g_workspace[ws];
+  dim3 grid(plan.blocks), block(GEMM_THREADS);
+  const int sel = (a.a_kmajor ? 2 : 0) | (a.b_kmajor ? 1 : 0);
+  switch (sel) {
+    case 0: hipLaunchKernelGGL((dgemm_streamk_kernel<false, false>), grid, block, 0, s, p); break;
+    case 1: hipLaunchKernelGGL((dgemm_streamk_kernel<false, true>), grid, block, 0, s, p); break;
+    case 2: hipLaunchKernelGGL((dgemm_streamk_kernel<true, false>), grid, block, 0, s, p); break;
+    case 3: hipLaunchKernelGGL((dgemm_streamk_kernel<true, true>), grid, block, 0, s, p); break;
+  }
+  if (plan.nfix)
+    hipLaunchKernelGGL(streamk_fixup_kernel, dim3(plan.nfix), dim3(256), 0, s, p, plan.fix_tile, plan.fix_ptr,
+                       plan.fix_slot);
+  GP_HIP(hipGetLastError());
+  return 0;
+}
+
+}  // namespace gpfit

@@ -91,13 +91,15 @@ class GPFitEngine:
         return torch.tensor(list(buf), dtype=torch.bool), int(d.value)
 
     def fit_eval(self, theta, lower, upper, n_px_side, X, r, m, V, logA, lambda0, want_grad=True,
-                 want_vectors=True):
+                 want_vectors=True, reuse_V=False):
         """One evaluation of the M-step closure (utils.py:2017-2112), full-rank regime.
 
         Returns a dict with ``loss`` (= -logmarginal), ``loglik``, ``KL``, ``grad`` (dict in the
         reference's key order, d loss / d theta), diagnostics, and the device vectors
         ``lam_m, lam_var, f``.  Out-of-box theta returns loss = inf and grad = inf (reference
-        behaviour); a failed Cholesky raises ``GpfitError``."""
+        behaviour); a failed Cholesky raises ``GpfitError``.  ``reuse_V=True`` promises that V is
+        the matrix of the previous call on this engine (constant during an M-step) so that its
+        factorisation is not repeated."""
         rows, cols = _grid(n_px_side)
         X, r, m, V = self._dev(X, "X"), self._dev(r, "r"), self._dev(m, "m"), self._dev(V, "V")
         N = X.shape[0]
@@ -115,7 +117,7 @@ class GPFitEngine:
         up = _lib.darr(theta_vec(upper)) if upper is not None else None
         rc = self.lib.gpfit_fit_eval(self._ctx, self._stream(), _lib.darr(theta_vec(theta)), lo, up, rows, cols,
                                      X.data_ptr(), X.stride(0), N, r.data_ptr(), m.data_ptr(), V.data_ptr(),
-                                     V.stride(0), float(logA), float(lambda0), 1 if want_grad else 0, out,
+                                     V.stride(0), float(logA), float(lambda0), (1 if want_grad else 0) | (2 if reuse_V else 0), out,
                                      ptrs[0], ptrs[1], ptrs[2])
         if rc > 0:
             raise _lib.GpfitError(f"gpfit_fit_eval: {_lib.last_error()} (info={rc})")

@@ -834,6 +834,7 @@ def varGP(x, r, **kwargs):
                     V_orig = matmul(B, matmul(V_b, B, transB=True))
                     V_orig = (V_orig + V_orig.T) * 0.5
                 mcalls = [0]
+                v_factored = [False]
 
                 def closure_hyperparams():
                     mcalls[0] += 1
@@ -852,7 +853,8 @@ def varGP(x, r, **kwargs):
                         e = get_engine(nt, nx, nx)
                         res = e.fit_eval(theta, theta_lower_lims, theta_higher_lims, n_px_side, x, r, m_orig, V_orig,
                                          _scalar(f_params['logA']), _scalar(_lambda0_of(f_params)), want_grad=True,
-                                         want_vectors=False)
+                                         want_vectors=False, reuse_V=v_factored[0])
+                        v_factored[0] = True  # V is constant for the rest of this M-step
                         loss, grad = res['loss'], res['grad']
                     else:
                         loss, grad = _closure_general(theta, lims, n_px_side, x, xtilde, r, B, m_b, V_b, f_params,

@@ -94,6 +94,8 @@ int gpfit_acosker_diag(gpfit_ctx* ctx, void* stream, double sigma0, const double
  * out_host[16] (HOST): 0 loss = -(loglik - KL), 1 loglik, 2 KL, 3..8 d loss/d theta (dict order),
  *   9 log|K~|, 10 log|V|, 11 tr(K~^-1 V), 12 m^T K~^-1 m, 13 masked pixel count,
  *   14 info(K~), 15 info(V).
+ * want_grad: bit 0 = compute the gradients; bit 1 = V is unchanged since the previous call on
+ * this context (constant during an M-step): reuse its Cholesky factor and log-det.
  * lam_m/lam_var/f (device, [N]) may be NULL.  Synchronises `stream` before returning.
  * Returns 0; -2 when theta is outside [lower, upper] (out_host[0] = +inf and gradients
  * +inf, exactly what the reference closure hands to L-BFGS); > 0 LAPACK info. */

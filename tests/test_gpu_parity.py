@@ -227,3 +227,16 @@ def test_sharded_cells_driver_on_one_gpu(dev):
     assert table.shape == (cells, 7)
     assert np.abs(table[:, 0] - exp[:, 0]).max() <= 1e-9 * np.abs(exp[:, 0]).max()
     assert np.abs(table[:, 1:] - exp[:, 1:]).max() <= 1e-6 * np.abs(exp[:, 1:]).max()
+
+
+def test_reuse_of_V_factor_is_exact(dev):
+    """reuse_V=True (V constant during an M-step) must give bit-identical results."""
+    grid, X, r, m, V, th1 = synthetic_case(384, 64)
+    eng = engine(384, 64)
+    args = (LOWER, UPPER, grid, X.to(dev), r.to(dev), m.to(dev), V.to(dev), LOGA, LAM0)
+    a = eng.fit_eval(th1, *args)
+    th2 = dict(th1)
+    th2["Amp"] *= 1.01
+    b = eng.fit_eval(th2, *args, reuse_V=True)
+    c = eng.fit_eval(th2, *args, reuse_V=False)
+    assert b["loss"] == c["loss"] and b["grad"] == c["grad"] and b["logdet_V"] == a["logdet_V"]
