@@ -240,3 +240,23 @@ def test_reuse_of_V_factor_is_exact(dev):
     b = eng.fit_eval(th2, *args, reuse_V=True)
     c = eng.fit_eval(th2, *args, reuse_V=False)
     assert b["loss"] == c["loss"] and b["grad"] == c["grad"] and b["logdet_V"] == a["logdet_V"]
+
+
+@pytest.mark.parametrize("N,d,grid", [(3, 4, (2, 2)), (2, 1, (1, 1)), (129, 9, (3, 3)), (257, 36, (6, 6))])
+def test_tiny_and_ragged_sizes(dev, N, d, grid):
+    """Sizes far from the 128 / 32 padding quanta, down to a 1-pixel image."""
+    grid, X, r, m, V, th1 = synthetic_case(N, d, grid)
+    loss, grad, p = orc.mstep_closure_cholesky(th1, LOWER, UPPER, grid, X, r, m, V, LOGA, LAM0, want_parts=True)
+    res = gpu_eval(dev, th1, grid, X, r, m, V)
+    assert_close(res, loss, p["loglik"], p["KL"], grad, p["lam_m"], p["lam_var"], p["f"])
+
+
+def test_singular_kernel_matrix_reports_info(dev):
+    """Exactly duplicated stimuli make K~ singular: the Cholesky of K~ must fail loudly with a
+    LAPACK-style info, not return garbage (the reference would truncate such directions)."""
+    grid, X, r, m, V, th1 = synthetic_case(256, 16)
+    X = X.clone()
+    X[200:] = X[:56]
+    V = torch.eye(256, dtype=torch.float64)
+    with pytest.raises(_lib.GpfitError, match="Cholesky of K_tilde"):
+        gpu_eval(dev, th1, grid, X, r, m, V)
