@@ -210,13 +210,16 @@ def main():
         eng.set_profile(False)
         gemm_tflops = prof["gemm_flops"] / (prof["gemm_ms"] * 1e-3) / 1e12 if prof["gemm_ms"] > 0 else 0.0
         roofline = {
-            "bound": "mfma", "kernel": "dgemm_mfma_kernel (fp64 v_mfma_f64_16x16x4, all GEMM/SYRK/TRSM/TRTRI panels)",
+            "bound": "mfma", "kernel": "dgemm_mfma_kernel<*,*,*,128> + dgemm_streamk_kernel (fp64 v_mfma_f64_16x16x4; the "
+                                       "128-tile GEMM/SYRK/TRSM/TRTRI launches)",
             "achieved": round(gemm_tflops, 2), "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": round(gemm_tflops / FP64_MFMA_PEAK_TFLOPS, 4), "traffic": profiled_traffic(),
             "launches_per_fit": prof["gemm_launches"],
             "avg_launch_ms": round(prof["gemm_ms"] / max(1, prof["gemm_launches"]), 4),
-            "flops_executed_per_fit": prof["gemm_flops"] + prof["gram_flops"],
+            "flops_executed_per_fit": prof["gemm_flops"] + prof["small_gemm_flops"] + prof["gram_flops"],
             "gemm_ms_per_fit": round(prof["gemm_ms"], 3), "leaf_ms_per_fit": round(prof["leaf_ms"], 3),
+            "small_tile_gemm": {"launches_per_fit": prof["small_gemm_launches"], "ms_per_fit": round(prof["small_gemm_ms"], 3),
+                                "tflops": round(prof["small_gemm_flops"] / max(prof["small_gemm_ms"], 1e-9) / 1e9, 2)},
             "gram_ms_per_fit": round(prof["gram_ms"], 3),
             "unit_algorithmic_flops": F,
             "unit_achieved_tflops": round(F * fits_per_s / world / 1e12, 2),

@@ -39,7 +39,7 @@ void prof_end(gpfit_ctx* c) {
   if (g_prof != c) return;
   g_prof = nullptr;
   (void)hipDeviceSynchronize();
-  double ms[3] = {0, 0, 0}, fl[3] = {0, 0, 0}, cnt[3] = {0, 0, 0};
+  double ms[4] = {0, 0, 0, 0}, fl[4] = {0, 0, 0, 0}, cnt[4] = {0, 0, 0, 0};
   for (auto& r : c->prof) {
     float t = 0.f;
     (void)hipEventElapsedTime(&t, r.a, r.b);
@@ -53,6 +53,7 @@ void prof_end(gpfit_ctx* c) {
   c->prof_out[0] = ms[0]; c->prof_out[1] = fl[0]; c->prof_out[2] = cnt[0];
   c->prof_out[3] = ms[1]; c->prof_out[4] = cnt[1];
   c->prof_out[5] = ms[2]; c->prof_out[6] = fl[2]; c->prof_out[7] = cnt[2];
+  c->prof_out[8] = ms[3]; c->prof_out[9] = fl[3]; c->prof_out[10] = cnt[3];
 }
 
 ProfScope::ProfScope(hipStream_t s_, double flops_, int kind_) : s(s_), flops(flops_), kind(kind_) {
@@ -99,7 +100,8 @@ static int gemm(hipStream_t s, int a_kmajor, int b_kmajor, int M, int N, int K, 
   g.a_kmajor = a_kmajor; g.b_kmajor = b_kmajor;
   g.out_lower = out_lower; g.a_tri = a_tri; g.b_tri = b_tri;
   g.batch = 1; g.split_k = 1; g.reverse = reverse; g.workspace = ws;
-  ProfScope ps(s, g_prof ? gemm_flops(g) : 0.0, 0);
+  // profile kind 0: the 128-tile kernel family (the dominant kernel), 3: the small-tile instances
+  ProfScope ps(s, g_prof ? gemm_flops(g) : 0.0, (g_prof && gemm_pick_tile(g) != TILE) ? 3 : 0);
   return launch_gemm(g, s);
 }
 
@@ -267,9 +269,9 @@ int gpfit_set_profile(gpfit_ctx* c, int on) {
 
 double gpfit_last_enqueue_ms(gpfit_ctx* c) { return c ? c->last_enqueue_ms : -1.0; }
 
-int gpfit_get_profile(gpfit_ctx* c, double* out8) {
-  if (!c || !out8) return -3;
-  for (int i = 0; i < 8; ++i) out8[i] = c->prof_out[i];
+int gpfit_get_profile(gpfit_ctx* c, double* out12) {
+  if (!c || !out12) return -3;
+  for (int i = 0; i < 12; ++i) out12[i] = c->prof_out[i];
   return 0;
 }
 
@@ -403,7 +405,7 @@ int gpfit_fit_eval(gpfit_ctx* c, void* stream, const double* theta, const double
       g.alpha = 1.0; g.beta = 0.0; g.a_kmajor = 1; g.b_kmajor = 1;
       g.batch = 1; g.split_k = c->split_k_M; g.sC = (int64_t)dp * dp;
       {
-        ProfScope ps(s, g_prof ? gemm_flops(g) : 0.0, 0);
+        ProfScope ps(s, g_prof ? gemm_flops(g) : 0.0, (g_prof && gemm_pick_tile(g) != TILE) ? 3 : 0);
         GP_TRY(launch_gemm(g, s));
       }
       GP_TRY(launch_reduce_slices(c->Mpart, (int64_t)dp * dp, c->split_k_M, c->Mmat, (int64_t)dp * dp, s));
