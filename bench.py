@@ -31,6 +31,7 @@ from gaussian_processes_amd import synthetic as syn  # noqa: E402
 from gaussian_processes_amd.engine import GPFitEngine, fits_flops  # noqa: E402
 
 FP64_MFMA_PEAK_TFLOPS = 78.6  # MI355X dense fp64 matrix peak (AMD datasheet; rocBLAS dgemm reaches 76.7 on-box)
+FP32_MFMA_PEAK_TFLOPS = 157.3  # f32-input MFMA peak (MI355X_MICROARCH.md, chip-level parameters)
 
 
 def log(msg):
@@ -136,6 +137,8 @@ def main():
     ap.add_argument("--cpu-sample-n", type=int, default=4096)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-grad", action="store_true", help="forward-only unit (not the headline metric)")
+    ap.add_argument("--dtype", choices=["f64", "f32"], default="f64",
+                    help="f64 = the reference's precision (headline); f32 = the theta-grid configuration's precision")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -176,6 +179,9 @@ def main():
         log("inputs resident; warm-up")
     logA, lam0 = syn.F_PARAMS["logA"], syn.F_PARAMS["lambda0"]
     want_grad = not args.no_grad
+    if args.dtype == "f32":
+        X, r, m, V = X.float(), r.float(), m.float(), V.float()
+    peak = FP64_MFMA_PEAK_TFLOPS if args.dtype == "f64" else FP32_MFMA_PEAK_TFLOPS
 
     def step():
         return eng.fit_eval(th1, lower, upper, grid, X, r, m, V, logA, lam0, want_grad=want_grad,
@@ -210,10 +216,10 @@ def main():
         eng.set_profile(False)
         gemm_tflops = prof["gemm_flops"] / (prof["gemm_ms"] * 1e-3) / 1e12 if prof["gemm_ms"] > 0 else 0.0
         roofline = {
-            "bound": "mfma", "kernel": "dgemm_mfma_kernel<*,*,*,128> + dgemm_streamk_kernel (fp64 v_mfma_f64_16x16x4; the "
+            "bound": "mfma", "kernel": "gemm_mfma_kernel<R,*,*,*,128> + gemm_streamk_kernel<R,..> (v_mfma_f64_16x16x4_f64 / v_mfma_f32_16x16x4_f32; the "
                                        "128-tile GEMM/SYRK/TRSM/TRTRI launches)",
-            "achieved": round(gemm_tflops, 2), "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(gemm_tflops / FP64_MFMA_PEAK_TFLOPS, 4), "traffic": profiled_traffic(),
+            "achieved": round(gemm_tflops, 2), "peak": peak, "unit": "TFLOP/s",
+            "frac": round(gemm_tflops / peak, 4), "traffic": profiled_traffic() if args.dtype == "f64" else None,
             "launches_per_fit": prof["gemm_launches"],
             "avg_launch_ms": round(prof["gemm_ms"] / max(1, prof["gemm_launches"]), 4),
             "flops_executed_per_fit": prof["gemm_flops"] + prof["small_gemm_flops"] + prof["gram_flops"],
@@ -223,20 +229,20 @@ def main():
             "gram_ms_per_fit": round(prof["gram_ms"], 3),
             "unit_algorithmic_flops": F,
             "unit_achieved_tflops": round(F * fits_per_s / world / 1e12, 2),
-            "unit_frac_of_peak": round(F * fits_per_s / world / 1e12 / FP64_MFMA_PEAK_TFLOPS, 4),
+            "unit_frac_of_peak": round(F * fits_per_s / world / 1e12 / peak, 4),
         }
         out = {
-            "metric": "GP fits/sec (kernel+chol+solve+grad loglik) at N=8192 d=256",
+            "metric": "GP fits/sec (kernel+chol+solve+grad loglik) at N=8192 d=256" + ("" if args.dtype == "f64" else " [fp32 instance]"),
             "value": round(fits_per_s, 4), "unit": "fits/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"N={N} d={d} single cell fp64, one M-step closure evaluation with 6 gradients "
                                    "(BASELINE configs[2], headline)" if want_grad else f"N={N} d={d} forward only",
                        "N": N, "d": d, "cells_per_gpu": 1, "parallelism": f"independent cells x{world}, X broadcast once over RCCL"},
             "loss": res["loss"],
             "roofline": roofline,
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.dtype == "f64":
             cb = cpu_baseline(args.cpu_sample_n, d)
             scale = (N / cb["n"]) ** 3
             out["cpu_baseline"] = {

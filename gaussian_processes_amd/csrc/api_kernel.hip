@@ -70,13 +70,13 @@ int gpfit_acosker(gpfit_ctx* c, void* stream, double sigma0, const double* x1, i
   const bool square = (n1 == n2);
   const double s0sq = sigma0 * sigma0;
   GP_TRY(launch_pad_copy(C, ldC, (int)d, (int)d, c->Cmat, dp, dp, dp, s));
-  GP_TRY(launch_gather(x1, ld1, (int)n1, nullptr, (int)d, dp, np1, c->Xt, np1, nullptr, 0, s));
+  GP_TRY(launch_gather<double>(x1, ld1, (int)n1, nullptr, (int)d, dp, np1, c->Xt, np1, nullptr, 0, s));
   GP_TRY(gemm_kk(s, dp, np1, dp, c->Cmat, dp, c->Xt, np1, c->XCt, np1));
   GP_TRY(launch_qvec(c->Xt, c->XCt, np1, dp, (int)n1, np1, s0sq, c->Kvec, c->q, s));
   const double* Xt2 = c->Xt;
   const double* q2 = c->q;
   if (!same) {
-    GP_TRY(launch_gather(x2, ld2, (int)n2, nullptr, (int)d, dp, np2, c->Xt2, np2, nullptr, 0, s));
+    GP_TRY(launch_gather<double>(x2, ld2, (int)n2, nullptr, (int)d, dp, np2, c->Xt2, np2, nullptr, 0, s));
     GP_TRY(gemm_kk(s, dp, np2, dp, c->Cmat, dp, c->Xt2, np2, c->XCt2, np2));
     GP_TRY(launch_qvec(c->Xt2, c->XCt2, np2, dp, (int)n2, np2, s0sq, c->hvec, c->q2, s));
     Xt2 = c->Xt2;
@@ -133,7 +133,7 @@ int gpfit_acosker_diag(gpfit_ctx* c, void* stream, double sigma0, const double* 
   }
   const double s0sq = sigma0 * sigma0;
   GP_TRY(launch_pad_copy(C, ldC, (int)d, (int)d, c->Cmat, dp, dp, dp, s));
-  GP_TRY(launch_gather(x1, ld1, (int)n1, nullptr, (int)d, dp, np1, c->Xt, np1, nullptr, 0, s));
+  GP_TRY(launch_gather<double>(x1, ld1, (int)n1, nullptr, (int)d, dp, np1, c->Xt, np1, nullptr, 0, s));
   GP_TRY(gemm_kk(s, dp, np1, dp, c->Cmat, dp, c->Xt, np1, c->XCt, np1));
   GP_TRY(launch_qvec(c->Xt, c->XCt, np1, dp, (int)n1, np1, s0sq, c->Kvec, c->q, s));
   GP_HIP(hipMemcpyAsync(Kvec, c->Kvec, (size_t)n1 * sizeof(double), hipMemcpyDeviceToDevice, s));  // utils.py:1029

@@ -12,7 +12,7 @@ namespace gpfit {
 constexpr double PI32 = 3.1415927410125732;
 
 constexpr int TILE = 128;  // GEMM block tile (M and N) and Cholesky leaf size
-constexpr int KTILE = 16;  // GEMM K step staged through LDS
+constexpr int KTILE = 16;  // fp64 GEMM K step staged through LDS (fp32: 32, see ktile_of)
 
 void set_error(const std::string& msg);
 
@@ -27,23 +27,24 @@ void set_error(const std::string& msg);
 
 inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
 
-// ---- fp64 MFMA GEMM -------------------------------------------------------------
+// ---- MFMA GEMM (fp64, and fp32 for the theta-grid configuration) ----------------------
 // C[M,N] = alpha * op(A)[M,K] * op(B)[K,N] + beta * C        (row-major storage)
 //   a_kmajor = 0 : A stored [M][K] (k contiguous)   element (m,k) at A[m*lda + k]
 //   a_kmajor = 1 : A stored [K][M] (m contiguous)   element (m,k) at A[k*lda + m]
 //   b_kmajor = 1 : B stored [K][N] (n contiguous)   element (k,n) at B[k*ldb + n]
 //   b_kmajor = 0 : B stored [N][K] (k contiguous)   element (k,n) at B[n*ldb + k]
-// Triangular structure is exploited per 128-tile:
-//   out_lower   : only tiles with tj <= ti are computed / written (M == N)
-//   (tri k ranges are taken per block tile of the size the launcher picks)
+// Triangular structure is exploited per block tile:
+//   out_lower   : only the 128-blocks on/below the block diagonal are computed / written (M == N)
 //   a_tri/b_tri : 0 dense, 1 op() is lower triangular, 2 op() is upper triangular
 //                 (restricts each tile's k range; the skipped part must hold zeros or is
 //                  simply never read)
-// K must be a multiple of 16; M, N arbitrary (edges are predicated); lda/ldb/ldc even.
-struct GemmArgs {
-  const double* A;
-  const double* B;
-  double* C;
+// K must be a multiple of the K step (16 for fp64, 32 for fp32); M, N arbitrary (edges are
+// predicated); lda/ldb multiples of 16 bytes.
+template <typename R>
+struct GemmArgsT {
+  const R* A;
+  const R* B;
+  R* C;
   int64_t lda, ldb, ldc;
   int M, N, K;
   double alpha, beta;
@@ -58,24 +59,30 @@ struct GemmArgs {
   int workspace;             // stream-K partial-tile workspace to use (0 main stream, 1 aux stream)
   int tile_limit;            // >0: launch only the first tile_limit tiles of the walk (stream-K head)
 };
-int launch_gemm(const GemmArgs& a, hipStream_t s);
-int gemm_pick_tile(const GemmArgs& a);
+using GemmArgs = GemmArgsT<double>;
+
+// K step staged through LDS: 16 KiB per operand per stage at T = 128 for either type
+template <typename R> constexpr int ktile_of() { return 128 / (int)sizeof(R); }
+
+template <typename R> int launch_gemm(const GemmArgsT<R>& a, hipStream_t s);
+template <typename R> int gemm_pick_tile(const GemmArgsT<R>& a);   // block tile the launcher will use (128 / 64 / 32)
 // stream-K schedule for large 128-tile launches (gemm_streamk.hip): 0 issued, 1 not applicable
-int launch_gemm_streamk(const GemmArgs& a, hipStream_t s);
-int launch_gemm_plain(const GemmArgs& a, hipStream_t s);  // data-parallel launch, no stream-K  // block tile the launcher will use (128 / 64 / 32)
+template <typename R> int launch_gemm_streamk(const GemmArgsT<R>& a, hipStream_t s);
+template <typename R> int launch_gemm_plain(const GemmArgsT<R>& a, hipStream_t s);  // data-parallel launch, no stream-K
 
 // Arc-cosine Gram matrix from the k-major, zero-padded operands XCt[Kd][ld1], Xt[Kd][ld2]:
 //   G = XCt^T Xt + s0^2 ; c = clip(G/(q1 q2 + 1e-7)) ; K = q1 q2 J(c)
 // np1/np2: padded extents (multiples of 128) that the loads may touch; nv1/nv2: valid
 // extents that are stored.  `lower`: only tiles on/below the diagonal (square case).
 // `pad_identity`: rows/cols >= nv get the identity (Kout must then hold np1 x np2).
-struct GramArgs {
-  const double* XCt;
-  const double* Xt;
-  const double* q1;   // [np1]
-  const double* q2;   // [np2]
-  double* Kout;       // [..][ldk]
-  double* Cos;        // same shape as Kout, or nullptr
+template <typename R>
+struct GramArgsT {
+  const R* XCt;
+  const R* Xt;
+  const R* q1;   // [np1]
+  const R* q2;   // [np2]
+  R* Kout;       // [..][ldk]
+  R* Cos;        // same shape as Kout, or nullptr
   int64_t ld1, ld2, ldk;
   int64_t ldcos;      // leading dimension of Cos (0: same as ldk)
   int np1, np2, nv1, nv2, Kd;
@@ -83,6 +90,7 @@ struct GramArgs {
   int lower;
   int pad_identity;
 };
-int launch_gram(const GramArgs& a, hipStream_t s);
+using GramArgs = GramArgsT<double>;
+template <typename R> int launch_gram(const GramArgsT<R>& a, hipStream_t s);
 
 }  // namespace gpfit

@@ -42,6 +42,7 @@ struct gpfit_ctx {
   int cur_n = 0, cur_np = 0, cur_d = 0, cur_dp = 0;
   bool lv_valid = false;  // LVbuf / scal[40] hold the factor and log-det of the last V
   int lv_n = 0;
+  int lv_bytes = 0;       // element size the cached factor was computed in
 };
 
 namespace gpfit {
@@ -54,20 +55,23 @@ struct ProfScope {
   ProfScope(hipStream_t s, double flops, int kind);
   ~ProfScope();
 };
-double gemm_flops(const GemmArgs& g);
+template <typename R> double gemm_flops(const GemmArgsT<R>& g);
 
-struct CholBufs {
-  double* A;    // input, lower triangle; destroyed
-  double* L;    // output factor
-  double* Li;   // output inverse blocks (full inverse when need_inv at the top)
-  double* Tmp;  // scratch, same shape
+template <typename R>
+struct CholBufsT {
+  R* A;    // input, lower triangle; destroyed
+  R* L;    // output factor
+  R* Li;   // output inverse blocks (full inverse when need_inv at the top)
+  R* Tmp;  // scratch, same shape
   int64_t ld;
   int* info;
   int ws = 0;   // stream-K workspace id (1 for the factorisation running on the aux stream)
 };
+using CholBufs = CholBufsT<double>;
 // Recursive blocked Cholesky of the n x n diagonal block at offset r0 (n a multiple of 128),
 // built entirely from the MFMA GEMM and the 128 x 128 leaf.  With need_inv the full inverse of
 // the factor is assembled on the way (L^-1 costs n^3/3 more; without it only n^3/12).
-int potrf_rec(const CholBufs& B, int r0, int n, bool need_inv, hipStream_t s);
+template <typename R>
+int potrf_rec(const CholBufsT<R>& B, int r0, int n, bool need_inv, hipStream_t s);
 
 }  // namespace gpfit

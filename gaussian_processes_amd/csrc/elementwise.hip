@@ -38,13 +38,14 @@ __device__ __forceinline__ double lin_pm1(int i, int n) {
 }
 
 // ------------------------------------------------------------------ localker
+template <typename R>
 __global__ void localker_kernel(Theta th, const int* __restrict__ pix, int d, int dp, int n_rows, int n_cols,
-                                double* __restrict__ C, int64_t ldc, double* __restrict__ dC) {
+                                R* __restrict__ C, int64_t ldc, R* __restrict__ dC) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   const int i = blockIdx.y * blockDim.y + threadIdx.y;
   if (i >= dp || j >= dp) return;
   if (i >= d || j >= d) {
-    C[(int64_t)i * ldc + j] = 0.0;
+    C[(int64_t)i * ldc + j] = (R)0;
     return;
   }
   const int pi = pix[i], pj = pix[j];
@@ -60,36 +61,37 @@ __global__ void localker_kernel(Theta th, const int* __restrict__ pix, int d, in
   const double cij = th.amp * ai * es * aj;             // :895
   const double cji = th.amp * aj * es * ai;
   const double c = (cij + cji) / 2.0;                   // :898
-  C[(int64_t)i * ldc + j] = c;
+  C[(int64_t)i * ldc + j] = (R)c;
   if (dC) {
     const int64_t dd = (int64_t)d * d, o = (int64_t)i * d + j;
-    dC[o] = c / th.amp;                                           // Amp        :902
-    dC[dd + o] = c * (lai + laj);                                 // -2log2beta :907
-    dC[2 * dd + o] = c * ls;                                      // -log2rho2  :909
-    dC[3 * dd + o] = 2.0 * th.eb * c * (xi + xj - 2.0 * th.eps0x);  // eps_0x   :904
-    dC[4 * dd + o] = 2.0 * th.eb * c * (yi + yj - 2.0 * th.eps0y);  // eps_0y   :905
+    dC[o] = (R)(c / th.amp);                                           // Amp        :902
+    dC[dd + o] = (R)(c * (lai + laj));                                 // -2log2beta :907
+    dC[2 * dd + o] = (R)(c * ls);                                      // -log2rho2  :909
+    dC[3 * dd + o] = (R)(2.0 * th.eb * c * (xi + xj - 2.0 * th.eps0x));  // eps_0x   :904
+    dC[4 * dd + o] = (R)(2.0 * th.eb * c * (yi + yj - 2.0 * th.eps0y));  // eps_0y   :905
   }
 }
 
-int launch_localker(const Theta& th, const int* pix, int d, int dp, int n_rows, int n_cols, double* C,
-                    int64_t ldc, double* dC, hipStream_t s) {
+template <typename R>
+int launch_localker(const Theta& th, const int* pix, int d, int dp, int n_rows, int n_cols, R* C, int64_t ldc,
+                    R* dC, hipStream_t s) {
   dim3 block(32, 8), grid((dp + 31) / 32, (dp + 7) / 8);
-  hipLaunchKernelGGL(localker_kernel, grid, block, 0, s, th, pix, d, dp, n_rows, n_cols, C, ldc, dC);
+  hipLaunchKernelGGL(localker_kernel<R>, grid, block, 0, s, th, pix, d, dp, n_rows, n_cols, C, ldc, dC);
   GP_HIP(hipGetLastError());
   return 0;
 }
 
 // ------------------------------------------------------------------ gather / transpose
-__global__ void gather_kernel(const double* __restrict__ X, int64_t ldx, int n, const int* __restrict__ pix,
-                              int d, double* __restrict__ Xt, int64_t ldt, double* __restrict__ Xm,
-                              int64_t ldm) {
-  __shared__ double tile[32][33];
+template <typename R>
+__global__ void gather_kernel(const R* __restrict__ X, int64_t ldx, int n, const int* __restrict__ pix, int d,
+                              R* __restrict__ Xt, int64_t ldt, R* __restrict__ Xm, int64_t ldm) {
+  __shared__ R tile[32][33];
   const int k0 = blockIdx.x * 32, n0 = blockIdx.y * 32;
   const int tx = threadIdx.x, ty = threadIdx.y;  // 32 x 8
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int nn = n0 + ty + 8 * r, k = k0 + tx;
-    double v = 0.0;
+    R v = 0;
     if (nn < n && k < d) v = X[(int64_t)nn * ldx + (pix ? pix[k] : k)];
     tile[ty + 8 * r][tx] = v;
     if (Xm) Xm[(int64_t)nn * ldm + k] = v;
@@ -102,72 +104,77 @@ __global__ void gather_kernel(const double* __restrict__ X, int64_t ldx, int n, 
   }
 }
 
-int launch_gather(const double* X, int64_t ldx, int n, const int* pix, int d, int dp, int np, double* Xt,
-                  int64_t ldt, double* Xm, int64_t ldm, hipStream_t s) {
+template <typename R>
+int launch_gather(const R* X, int64_t ldx, int n, const int* pix, int d, int dp, int np, R* Xt, int64_t ldt, R* Xm,
+                  int64_t ldm, hipStream_t s) {
   if (dp % 32 || np % 32) {
     set_error("launch_gather: padded extents must be multiples of 32");
     return -3;
   }
-  hipLaunchKernelGGL(gather_kernel, dim3(dp / 32, np / 32), dim3(32, 8), 0, s, X, ldx, n, pix, d, Xt, ldt, Xm,
+  hipLaunchKernelGGL(gather_kernel<R>, dim3(dp / 32, np / 32), dim3(32, 8), 0, s, X, ldx, n, pix, d, Xt, ldt, Xm,
                      ldm);
   GP_HIP(hipGetLastError());
   return 0;
 }
 
 // ------------------------------------------------------------------ q / Kvec
-__global__ void qvec_kernel(const double* __restrict__ Xt, const double* __restrict__ XCt, int64_t ld, int dp,
-                            int n, int np, double s0sq, double* __restrict__ Kvec, double* __restrict__ q) {
+template <typename R>
+__global__ void qvec_kernel(const R* __restrict__ Xt, const R* __restrict__ XCt, int64_t ld, int dp, int n, int np,
+                            double s0sq, R* __restrict__ Kvec, R* __restrict__ q) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= np) return;
   if (i >= n) {
-    Kvec[i] = 1.0;
-    q[i] = 1.0;
+    Kvec[i] = (R)1;
+    q[i] = (R)1;
     return;
   }
   double h = 0.0;
-  for (int k = 0; k < dp; ++k) h += Xt[(int64_t)k * ld + i] * XCt[(int64_t)k * ld + i];
+  for (int k = 0; k < dp; ++k) h += (double)Xt[(int64_t)k * ld + i] * (double)XCt[(int64_t)k * ld + i];
   const double kv = h + s0sq;  // utils.py:1029
-  Kvec[i] = kv;
-  q[i] = sqrt(kv);             // utils.py:978
+  Kvec[i] = (R)kv;
+  q[i] = (R)sqrt(kv);          // utils.py:978
 }
 
-int launch_qvec(const double* Xt, const double* XCt, int64_t ld, int dp, int n, int np, double s0sq,
-                double* Kvec, double* q, hipStream_t s) {
-  hipLaunchKernelGGL(qvec_kernel, dim3((np + 255) / 256), dim3(256), 0, s, Xt, XCt, ld, dp, n, np, s0sq, Kvec, q);
+template <typename R>
+int launch_qvec(const R* Xt, const R* XCt, int64_t ld, int dp, int n, int np, double s0sq, R* Kvec, R* q,
+                hipStream_t s) {
+  hipLaunchKernelGGL(qvec_kernel<R>, dim3((np + 255) / 256), dim3(256), 0, s, Xt, XCt, ld, dp, n, np, s0sq, Kvec, q);
   GP_HIP(hipGetLastError());
   return 0;
 }
 
 // ------------------------------------------------------------------ pack / symmetrize
-__global__ void pack_lower_kernel(const double* __restrict__ src, int64_t lds, int n, double* __restrict__ dst,
-                                  int64_t ldd) {
+template <typename R>
+__global__ void pack_lower_kernel(const R* __restrict__ src, int64_t lds, int n, R* __restrict__ dst, int64_t ldd) {
   const int tj = blockIdx.x, ti = blockIdx.y;
   if (tj > ti) return;
   const int r0 = ti * TILE, c0 = tj * TILE;
   for (int e = threadIdx.x; e < TILE * TILE; e += blockDim.x) {
     const int i = r0 + (e >> 7), j = c0 + (e & 127);
-    double v;
+    R v;
     if (i < n && j < n) v = src[(int64_t)i * lds + j];
-    else v = (i == j) ? 1.0 : 0.0;
+    else v = (i == j) ? (R)1 : (R)0;
     dst[(int64_t)i * ldd + j] = v;
   }
 }
 
-int launch_pack_lower(const double* src, int64_t lds, int n, double* dst, int64_t ldd, int np, hipStream_t s) {
-  hipLaunchKernelGGL(pack_lower_kernel, dim3(np / TILE, np / TILE), dim3(256), 0, s, src, lds, n, dst, ldd);
+template <typename R>
+int launch_pack_lower(const R* src, int64_t lds, int n, R* dst, int64_t ldd, int np, hipStream_t s) {
+  hipLaunchKernelGGL(pack_lower_kernel<R>, dim3(np / TILE, np / TILE), dim3(256), 0, s, src, lds, n, dst, ldd);
   GP_HIP(hipGetLastError());
   return 0;
 }
 
-__global__ void symmetrize_kernel(double* __restrict__ A, int64_t lda, int n) {
-  __shared__ double tile[32][33];
+template <typename R>
+__global__ void symmetrize_kernel(R* __restrict__ A, int64_t lda, int n) {
+  __shared__ R tile[32][33];
   const int tj = blockIdx.x, ti = blockIdx.y;
   if (tj > ti) return;
   const int tx = threadIdx.x, ty = threadIdx.y;
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int i = ti * 32 + ty + 8 * r, j = tj * 32 + tx;
-    tile[ty + 8 * r][tx] = (i < n && j < n) ? A[(int64_t)i * lda + j] : 0.0;
+    tile[ty + 8 * r][tx] = (i < n && j < n) ? A[(int64_t)i * lda + j] : (R)0;
   }
   __syncthreads();
 #pragma unroll
@@ -178,37 +185,42 @@ __global__ void symmetrize_kernel(double* __restrict__ A, int64_t lda, int n) {
   }
 }
 
-int launch_symmetrize(double* A, int64_t lda, int n, hipStream_t s) {
+template <typename R>
+int launch_symmetrize(R* A, int64_t lda, int n, hipStream_t s) {
   const int t = (n + 31) / 32;
-  hipLaunchKernelGGL(symmetrize_kernel, dim3(t, t), dim3(32, 8), 0, s, A, lda, n);
+  hipLaunchKernelGGL(symmetrize_kernel<R>, dim3(t, t), dim3(32, 8), 0, s, A, lda, n);
   GP_HIP(hipGetLastError());
   return 0;
 }
 
 // ------------------------------------------------------------------ small reductions
-__global__ void logdet_kernel(const double* __restrict__ L, int64_t ldl, int n, double* __restrict__ out) {
+template <typename R>
+__global__ void logdet_kernel(const R* __restrict__ L, int64_t ldl, int n, double* __restrict__ out) {
   __shared__ double sh[17];
   double v = 0.0;
-  for (int i = threadIdx.x; i < n; i += blockDim.x) v += log(L[(int64_t)i * ldl + i]);
+  for (int i = threadIdx.x; i < n; i += blockDim.x) v += log((double)L[(int64_t)i * ldl + i]);
   v = block_sum(v, sh);
   if (threadIdx.x == 0) out[0] = 2.0 * v;  // utils.py:1278
 }
 
-int launch_logdet(const double* L, int64_t ldl, int n, double* out, hipStream_t s) {
-  hipLaunchKernelGGL(logdet_kernel, dim3(1), dim3(1024), 0, s, L, ldl, n, out);
+template <typename R>
+int launch_logdet(const R* L, int64_t ldl, int n, double* out, hipStream_t s) {
+  hipLaunchKernelGGL(logdet_kernel<R>, dim3(1), dim3(1024), 0, s, L, ldl, n, out);
   GP_HIP(hipGetLastError());
   return 0;
 }
 
-__global__ void sum_kernel(const double* __restrict__ x, int n, double scale, double* __restrict__ out) {
+template <typename R>
+__global__ void sum_kernel(const R* __restrict__ x, int n, double scale, double* __restrict__ out) {
   __shared__ double sh[17];
   double v = 0.0;
-  for (int i = threadIdx.x; i < n; i += blockDim.x) v += x[i];
+  for (int i = threadIdx.x; i < n; i += blockDim.x) v += (double)x[i];
   v = block_sum(v, sh);
   if (threadIdx.x == 0) out[0] = scale * v;
 }
 
-__global__ void frob_tile_kernel(const double* __restrict__ T, int64_t ldt, double* __restrict__ partial) {
+template <typename R>
+__global__ void frob_tile_kernel(const R* __restrict__ T, int64_t ldt, double* __restrict__ partial) {
   __shared__ double sh[17];
   int ti, tj;
   {
@@ -219,46 +231,49 @@ __global__ void frob_tile_kernel(const double* __restrict__ T, int64_t ldt, doub
     ti = i;
     tj = t - i * (i + 1) / 2;
   }
-  const double* base = T + (int64_t)ti * TILE * ldt + tj * TILE;
+  const R* base = T + (int64_t)ti * TILE * ldt + tj * TILE;
   double v = 0.0;
-  for (int e = threadIdx.x; e < TILE * TILE / 2; e += blockDim.x) {
-    const int i = e >> 6, j = (e & 63) * 2;
-    const double2 x = *reinterpret_cast<const double2*>(base + (int64_t)i * ldt + j);
-    v += x.x * x.x + x.y * x.y;
+  for (int e = threadIdx.x; e < TILE * TILE; e += blockDim.x) {
+    const double x = (double)base[(int64_t)(e >> 7) * ldt + (e & 127)];
+    v += x * x;
   }
   v = block_sum(v, sh);
   if (threadIdx.x == 0) partial[blockIdx.x] = v;
 }
 
-int launch_frob_lower(const double* T, int64_t ldt, int np, double* out, double* partial, hipStream_t s) {
+template <typename R>
+int launch_frob_lower(const R* T, int64_t ldt, int np, double* out, double* partial, hipStream_t s) {
   const int t = np / TILE, nt = t * (t + 1) / 2;
-  hipLaunchKernelGGL(frob_tile_kernel, dim3(nt), dim3(256), 0, s, T, ldt, partial);
-  hipLaunchKernelGGL(sum_kernel, dim3(1), dim3(1024), 0, s, partial, nt, 1.0, out);
+  hipLaunchKernelGGL(frob_tile_kernel<R>, dim3(nt), dim3(256), 0, s, T, ldt, partial);
+  hipLaunchKernelGGL(sum_kernel<double>, dim3(1), dim3(1024), 0, s, partial, nt, 1.0, out);
   GP_HIP(hipGetLastError());
   return 0;
 }
 
-__global__ void trmv_lower_kernel(const double* __restrict__ L, int64_t ldl, int np, const double* __restrict__ x,
-                                  double* __restrict__ y) {
+template <typename R>
+__global__ void trmv_lower_kernel(const R* __restrict__ L, int64_t ldl, int np, const R* __restrict__ x,
+                                  R* __restrict__ y) {
   const int lane = threadIdx.x & 63;
   const int i = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (i >= np) return;
-  const double* row = L + (int64_t)i * ldl;
+  const R* row = L + (int64_t)i * ldl;
   double v = 0.0;
-  for (int j = lane; j <= i; j += 64) v += row[j] * x[j];
+  for (int j = lane; j <= i; j += 64) v += (double)row[j] * (double)x[j];
   v = wave_sum(v);
-  if (lane == 0) y[i] = v;
+  if (lane == 0) y[i] = (R)v;
 }
 
-int launch_trmv_lower(const double* L, int64_t ldl, int np, const double* x, double* y, hipStream_t s) {
-  hipLaunchKernelGGL(trmv_lower_kernel, dim3((np + 3) / 4), dim3(256), 0, s, L, ldl, np, x, y);
+template <typename R>
+int launch_trmv_lower(const R* L, int64_t ldl, int np, const R* x, R* y, hipStream_t s) {
+  hipLaunchKernelGGL(trmv_lower_kernel<R>, dim3((np + 3) / 4), dim3(256), 0, s, L, ldl, np, x, y);
   GP_HIP(hipGetLastError());
   return 0;
 }
 
 // z_j = sum_{i >= j} L[i][j] x_i : block = 64 columns x one chunk of 512 rows
-__global__ void trmv_lower_t_kernel(const double* __restrict__ L, int64_t ldl, int np,
-                                    const double* __restrict__ x, double* __restrict__ partial) {
+template <typename R>
+__global__ void trmv_lower_t_kernel(const R* __restrict__ L, int64_t ldl, int np, const R* __restrict__ x,
+                                    double* __restrict__ partial) {
   __shared__ double sh[4][64];
   const int c = threadIdx.x & 63, rl = threadIdx.x >> 6;
   const int j = blockIdx.x * 64 + c;
@@ -266,77 +281,80 @@ __global__ void trmv_lower_t_kernel(const double* __restrict__ L, int64_t ldl, i
   double v = 0.0;
   if (i1 > blockIdx.x * 64) {
     for (int i = i0 + rl; i < i1; i += 4)
-      if (i >= j) v += L[(int64_t)i * ldl + j] * x[i];
+      if (i >= j) v += (double)L[(int64_t)i * ldl + j] * (double)x[i];
   }
   sh[rl][c] = v;
   __syncthreads();
   if (rl == 0) partial[(int64_t)blockIdx.y * np + j] = sh[0][c] + sh[1][c] + sh[2][c] + sh[3][c];
 }
 
-__global__ void reduce_slices_kernel(const double* __restrict__ src, int64_t stride, int nslice,
-                                     double* __restrict__ dst, int64_t count) {
+template <typename RI, typename RO>
+__global__ void reduce_slices_kernel(const RI* __restrict__ src, int64_t stride, int nslice, RO* __restrict__ dst,
+                                     int64_t count) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= count) return;
   double v = 0.0;
-  for (int z = 0; z < nslice; ++z) v += src[(int64_t)z * stride + i];
-  dst[i] = v;
+  for (int z = 0; z < nslice; ++z) v += (double)src[(int64_t)z * stride + i];
+  dst[i] = (RO)v;
 }
 
-int launch_reduce_slices(const double* src, int64_t slice_stride, int nslice, double* dst, int64_t count,
-                         hipStream_t s) {
-  hipLaunchKernelGGL(reduce_slices_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, s, src,
+template <typename RI, typename RO>
+int launch_reduce_slices(const RI* src, int64_t slice_stride, int nslice, RO* dst, int64_t count, hipStream_t s) {
+  hipLaunchKernelGGL((reduce_slices_kernel<RI, RO>), dim3((unsigned)((count + 255) / 256)), dim3(256), 0, s, src,
                      slice_stride, nslice, dst, count);
   GP_HIP(hipGetLastError());
   return 0;
 }
 
-int launch_trmv_lower_t(const double* L, int64_t ldl, int np, const double* x, double* z, double* partial,
-                        hipStream_t s) {
+template <typename R>
+int launch_trmv_lower_t(const R* L, int64_t ldl, int np, const R* x, R* z, double* partial, hipStream_t s) {
   const int chunks = (np + 511) / 512;
-  hipLaunchKernelGGL(trmv_lower_t_kernel, dim3(np / 64, chunks), dim3(256), 0, s, L, ldl, np, x, partial);
+  hipLaunchKernelGGL(trmv_lower_t_kernel<R>, dim3(np / 64, chunks), dim3(256), 0, s, L, ldl, np, x, partial);
   GP_HIP(hipGetLastError());
   return launch_reduce_slices(partial, np, chunks, z, np, s);
 }
 
-__global__ void dot_kernel(const double* __restrict__ x, const double* __restrict__ y, int n,
-                           double* __restrict__ out) {
+template <typename R>
+__global__ void dot_kernel(const R* __restrict__ x, const R* __restrict__ y, int n, double* __restrict__ out) {
   __shared__ double sh[17];
   double v = 0.0;
-  for (int i = threadIdx.x; i < n; i += blockDim.x) v += x[i] * y[i];
+  for (int i = threadIdx.x; i < n; i += blockDim.x) v += (double)x[i] * (double)y[i];
   v = block_sum(v, sh);
   if (threadIdx.x == 0) out[0] = v;
 }
 
-int launch_dot(const double* x, const double* y, int n, double* out, hipStream_t s) {
-  hipLaunchKernelGGL(dot_kernel, dim3(1), dim3(1024), 0, s, x, y, n, out);
+template <typename R>
+int launch_dot(const R* x, const R* y, int n, double* out, hipStream_t s) {
+  hipLaunchKernelGGL(dot_kernel<R>, dim3(1), dim3(1024), 0, s, x, y, n, out);
   GP_HIP(hipGetLastError());
   return 0;
 }
 
 // ------------------------------------------------------------------ moments / rate / likelihood
-__global__ void moments_kernel(const double* __restrict__ Kvec, const double* __restrict__ q,
-                               const double* __restrict__ Cos, int64_t ldc, const double* __restrict__ V,
-                               int64_t ldv, const double* __restrict__ m, const double* __restrict__ r, int n,
-                               double A, double lambda0, double* __restrict__ lam_m,
-                               double* __restrict__ lam_var, double* __restrict__ f, double* __restrict__ wl,
+template <typename R>
+__global__ void moments_kernel(const R* __restrict__ Kvec, const R* __restrict__ q, const R* __restrict__ Cos,
+                               int64_t ldc, const R* __restrict__ V, int64_t ldv, const R* __restrict__ m,
+                               const R* __restrict__ r, int n, double A, double lambda0, R* __restrict__ lam_m,
+                               R* __restrict__ lam_var, R* __restrict__ f, R* __restrict__ wl,
                                double* __restrict__ scal) {
   __shared__ double sh[17];
   double s_rm = 0.0, s_r = 0.0, s_f = 0.0;
   for (int i = threadIdx.x; i < n; i += blockDim.x) {
-    const double c = Cos[(int64_t)i * ldc + i];
+    const double c = (double)Cos[(int64_t)i * ldc + i];
     const double delta = acos(c);
     const double J = (sqrt(1.0 - c * c) + PI32 * c - delta * c) / PI32;
-    const double kii = q[i] * q[i] * J;                     // K~_ii as the Gram kernel wrote it
-    const double lv = Kvec[i] - kii + V[(int64_t)i * ldv + i];  // utils.py:1101 with a = B, full rank
-    const double lm = m[i];                                 // utils.py:1090
+    const double qi = (double)q[i];
+    const double kii = qi * qi * J;                         // K~_ii as the Gram kernel wrote it
+    const double lv = (double)Kvec[i] - kii + (double)V[(int64_t)i * ldv + i];  // utils.py:1101, a = B, full rank
+    const double lm = (double)m[i];                         // utils.py:1090
     const double fi = exp(A * lm + 0.5 * A * A * lv + lambda0);  // utils.py:1138
     const double g = 1.0 - J - (PI32 - delta) * (1.0 - c) / PI32;
-    lam_m[i] = lm;
-    lam_var[i] = lv;
-    f[i] = fi;
-    wl[i] = -0.5 * A * A * fi * g;
-    s_rm += r[i] * lm;
-    s_r += r[i];
+    lam_m[i] = (R)lm;
+    lam_var[i] = (R)lv;
+    f[i] = (R)fi;
+    wl[i] = (R)(-0.5 * A * A * fi * g);
+    s_rm += (double)r[i] * lm;
+    s_r += (double)r[i];
     s_f += fi;
   }
   s_rm = block_sum(s_rm, sh);
@@ -349,22 +367,23 @@ __global__ void moments_kernel(const double* __restrict__ Kvec, const double* __
   }
 }
 
-int launch_moments(const double* Kvec, const double* q, const double* Cos, int64_t ldc, const double* V,
-                   int64_t ldv, const double* m, const double* r, int n, double A, double lambda0,
-                   double* lam_m, double* lam_var, double* f, double* wl, double* scal, hipStream_t s) {
-  hipLaunchKernelGGL(moments_kernel, dim3(1), dim3(1024), 0, s, Kvec, q, Cos, ldc, V, ldv, m, r, n, A, lambda0,
+template <typename R>
+int launch_moments(const R* Kvec, const R* q, const R* Cos, int64_t ldc, const R* V, int64_t ldv, const R* m,
+                   const R* r, int n, double A, double lambda0, R* lam_m, R* lam_var, R* f, R* wl, double* scal,
+                   hipStream_t s) {
+  hipLaunchKernelGGL(moments_kernel<R>, dim3(1), dim3(1024), 0, s, Kvec, q, Cos, ldc, V, ldv, m, r, n, A, lambda0,
                      lam_m, lam_var, f, wl, scal);
   GP_HIP(hipGetLastError());
   return 0;
 }
 
 // ------------------------------------------------------------------ adjoint pass (64 x 64 tiles)
-__global__ __launch_bounds__(256) void adjoint_kernel(const double* __restrict__ W, const double* __restrict__ Cos,
-                                                      int64_t ld, const double* __restrict__ b,
-                                                      const double* __restrict__ q, int n, int np,
-                                                      double* __restrict__ Aout, double* __restrict__ upart,
+template <typename R>
+__global__ __launch_bounds__(256) void adjoint_kernel(const R* __restrict__ W, const R* __restrict__ Cos, int64_t ld,
+                                                      const R* __restrict__ b, const R* __restrict__ q, int n,
+                                                      int np, R* __restrict__ Aout, double* __restrict__ upart,
                                                       double* __restrict__ vpart, double* __restrict__ sumA_part) {
-  __shared__ double tA[64][65];
+  __shared__ R tA[64][65];
   __shared__ double colsum[4][64];
   __shared__ double sh[17];
   int ti, tj;
@@ -379,7 +398,7 @@ __global__ __launch_bounds__(256) void adjoint_kernel(const double* __restrict__
   const bool diag = (ti == tj);
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;  // ty = wave
   const int j = tj * 64 + tx;
-  const double qj = q[j], bj = b[j];
+  const double qj = (double)q[j], bj = (double)b[j];
   double csum = 0.0, asum = 0.0;
   for (int rr = ty; rr < 64; rr += 4) {
     const int i = ti * 64 + rr;
@@ -387,18 +406,18 @@ __global__ __launch_bounds__(256) void adjoint_kernel(const double* __restrict__
     if (i < n && j < n) {
       // canonical storage is the lower triangle: in a diagonal tile read (j,i) when i < j
       const int64_t o = (diag && i < j) ? ((int64_t)j * ld + i) : ((int64_t)i * ld + j);
-      const double w = W[o] - 0.5 * b[i] * bj;
-      const double c = Cos[o];
+      const double w = (double)W[o] - 0.5 * (double)b[i] * bj;
+      const double c = (double)Cos[o];
       aw = w * (PI32 - acos(c)) / PI32;
       bm = w * sqrt(1.0 - c * c) / PI32;
     }
-    tA[rr][tx] = aw;
-    Aout[(int64_t)i * ld + j] = aw;
+    tA[rr][tx] = (R)aw;
+    Aout[(int64_t)i * ld + j] = (R)aw;
     asum += aw;
     // row sum over the 64 columns of this tile (one wave holds a whole row)
     const double rs = wave_sum(bm * qj);
     if (tx == 0) upart[(int64_t)tj * np + i] = rs;
-    csum += bm * q[i];
+    csum += bm * (double)q[i];
   }
   colsum[ty][tx] = csum;
   __syncthreads();
@@ -414,13 +433,14 @@ __global__ __launch_bounds__(256) void adjoint_kernel(const double* __restrict__
   if (threadIdx.x == 0) sumA_part[blockIdx.x] = diag ? asum : 2.0 * asum;
 }
 
+template <typename R>
 __global__ void adjoint_u_kernel(const double* __restrict__ upart, const double* __restrict__ vpart, int nt64,
-                                 const double* __restrict__ q, const double* __restrict__ wl, int n, int np,
-                                 double* __restrict__ tvec, double* __restrict__ uq) {
+                                 const R* __restrict__ q, const R* __restrict__ wl, int n, int np,
+                                 R* __restrict__ tvec, double* __restrict__ uq) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= np) return;
   if (i >= n) {
-    tvec[i] = 0.0;
+    tvec[i] = (R)0;
     uq[i] = 0.0;
     return;
   }
@@ -428,45 +448,46 @@ __global__ void adjoint_u_kernel(const double* __restrict__ upart, const double*
   double u = 0.0;
   for (int t = 0; t <= T; ++t) u += upart[(int64_t)t * np + i];
   for (int t = T + 1; t < nt64; ++t) u += vpart[(int64_t)t * np + i];
-  const double v = u / q[i];
+  const double v = u / (double)q[i];
   uq[i] = v;
-  tvec[i] = v - wl[i];
+  tvec[i] = (R)(v - (double)wl[i]);
 }
 
-int launch_adjoint(const double* W, const double* Cos, int64_t ld, const double* b, const double* q, int n,
-                   int np, double* Aout, double* upart, double* vpart, double* sumA_part, hipStream_t s) {
+template <typename R>
+int launch_adjoint(const R* W, const R* Cos, int64_t ld, const R* b, const R* q, int n, int np, R* Aout,
+                   double* upart, double* vpart, double* sumA_part, hipStream_t s) {
   const int t = np / 64, nt = t * (t + 1) / 2;
-  hipLaunchKernelGGL(adjoint_kernel, dim3(nt), dim3(256), 0, s, W, Cos, ld, b, q, n, np, Aout, upart, vpart,
+  hipLaunchKernelGGL(adjoint_kernel<R>, dim3(nt), dim3(256), 0, s, W, Cos, ld, b, q, n, np, Aout, upart, vpart,
                      sumA_part);
   GP_HIP(hipGetLastError());
   return 0;
 }
 
+template <typename R>
 int launch_adjoint_reduce(const double* upart, const double* vpart, const double* sumA_part, int ntile,
-                          int ntile_tri, const double* q, const double* wl, int n, int np, double* tvec,
+                          int ntile_tri, const R* q, const R* wl, int n, int np, R* tvec, double* uq,
                           double* scal_out, hipStream_t s) {
-  // uq is staged in the (now consumed) first row of upart's tail: caller provides tvec[np..2np)
-  double* uq = tvec + np;
-  hipLaunchKernelGGL(adjoint_u_kernel, dim3((np + 255) / 256), dim3(256), 0, s, upart, vpart, ntile, q, wl, n,
+  hipLaunchKernelGGL(adjoint_u_kernel<R>, dim3((np + 255) / 256), dim3(256), 0, s, upart, vpart, ntile, q, wl, n,
                      np, tvec, uq);
-  hipLaunchKernelGGL(sum_kernel, dim3(1), dim3(1024), 0, s, uq, n, 1.0, scal_out + 0);
-  hipLaunchKernelGGL(sum_kernel, dim3(1), dim3(1024), 0, s, wl, n, 1.0, scal_out + 1);
-  hipLaunchKernelGGL(sum_kernel, dim3(1), dim3(1024), 0, s, sumA_part, ntile_tri, 1.0, scal_out + 2);
+  hipLaunchKernelGGL(sum_kernel<double>, dim3(1), dim3(1024), 0, s, uq, n, 1.0, scal_out + 0);
+  hipLaunchKernelGGL(sum_kernel<R>, dim3(1), dim3(1024), 0, s, wl, n, 1.0, scal_out + 1);
+  hipLaunchKernelGGL(sum_kernel<double>, dim3(1), dim3(1024), 0, s, sumA_part, ntile_tri, 1.0, scal_out + 2);
   GP_HIP(hipGetLastError());
   return 0;
 }
 
-__global__ void rowscale_add_kernel(double* __restrict__ Y, int64_t ldy, const double* __restrict__ Xm,
-                                    int64_t ldm, const double* __restrict__ t, int dp) {
+template <typename R>
+__global__ void rowscale_add_kernel(R* __restrict__ Y, int64_t ldy, const R* __restrict__ Xm, int64_t ldm,
+                                    const R* __restrict__ t, int dp) {
   const int i = blockIdx.y;
-  const double ti = t[i];
+  const R ti = t[i];
   for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < dp; k += gridDim.x * blockDim.x)
     Y[(int64_t)i * ldy + k] += ti * Xm[(int64_t)i * ldm + k];
 }
 
-int launch_rowscale_add(double* Y, int64_t ldy, const double* Xm, int64_t ldm, const double* t, int np,
-                        int dp, hipStream_t s) {
-  hipLaunchKernelGGL(rowscale_add_kernel, dim3((dp + 255) / 256, np), dim3(256), 0, s, Y, ldy, Xm, ldm, t, dp);
+template <typename R>
+int launch_rowscale_add(R* Y, int64_t ldy, const R* Xm, int64_t ldm, const R* t, int np, int dp, hipStream_t s) {
+  hipLaunchKernelGGL(rowscale_add_kernel<R>, dim3((dp + 255) / 256, np), dim3(256), 0, s, Y, ldy, Xm, ldm, t, dp);
   GP_HIP(hipGetLastError());
   return 0;
 }
@@ -474,9 +495,10 @@ int launch_rowscale_add(double* Y, int64_t ldy, const double* Xm, int64_t ldm, c
 // ------------------------------------------------------------------ metric contraction
 // grad5[p] = sum_kl dC_p[k][l] M[k][l], dC_p rebuilt from C and the pixel coordinates
 // (utils.py:902-909), order Amp, -2log2beta, -log2rho2, eps_0x, eps_0y.
+template <typename R>
 __global__ void metric_contract_kernel(Theta th, const int* __restrict__ pix, int d, int n_rows, int n_cols,
-                                       const double* __restrict__ C, int64_t ldc, const double* __restrict__ M,
-                                       int64_t ldm, double* __restrict__ grad5) {
+                                       const R* __restrict__ C, int64_t ldc, const R* __restrict__ M, int64_t ldm,
+                                       double* __restrict__ grad5) {
   __shared__ double sh[17];
   double g[5] = {0, 0, 0, 0, 0};
   const int64_t total = (int64_t)d * d;
@@ -490,8 +512,8 @@ __global__ void metric_contract_kernel(Theta th, const int* __restrict__ pix, in
     const double laj = -th.eb * (dxj * dxj + dyj * dyj);
     const double ex = xj - xi, ey = yj - yi;
     const double ls = -th.er * (ex * ex + ey * ey);
-    const double c = C[(int64_t)i * ldc + j];
-    const double mm = M[(int64_t)i * ldm + j];
+    const double c = (double)C[(int64_t)i * ldc + j];
+    const double mm = (double)M[(int64_t)i * ldm + j];
     g[0] += (c / th.amp) * mm;
     g[1] += (c * (lai + laj)) * mm;
     g[2] += (c * ls) * mm;
@@ -505,9 +527,10 @@ __global__ void metric_contract_kernel(Theta th, const int* __restrict__ pix, in
   }
 }
 
-int launch_metric_contract(const Theta& th, const int* pix, int d, int n_rows, int n_cols, const double* C,
-                           int64_t ldc, const double* M, int64_t ldm, double* grad5, hipStream_t s) {
-  hipLaunchKernelGGL(metric_contract_kernel, dim3(1), dim3(1024), 0, s, th, pix, d, n_rows, n_cols, C, ldc, M,
+template <typename R>
+int launch_metric_contract(const Theta& th, const int* pix, int d, int n_rows, int n_cols, const R* C, int64_t ldc,
+                           const R* M, int64_t ldm, double* grad5, hipStream_t s) {
+  hipLaunchKernelGGL(metric_contract_kernel<R>, dim3(1), dim3(1024), 0, s, th, pix, d, n_rows, n_cols, C, ldc, M,
                      ldm, grad5);
   GP_HIP(hipGetLastError());
   return 0;
@@ -612,13 +635,15 @@ int launch_dk_metric(double* H, int64_t ldh, const double* Cos, int64_t ldc, con
   return 0;
 }
 
-__global__ void add_diag_kernel(double* __restrict__ A, int64_t lda, int n, double v) {
+template <typename R>
+__global__ void add_diag_kernel(R* __restrict__ A, int64_t lda, int n, double v) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) A[(int64_t)i * lda + i] += v;
+  if (i < n) A[(int64_t)i * lda + i] += (R)v;
 }
 
-int launch_add_diag(double* A, int64_t lda, int n, double v, hipStream_t s) {
-  hipLaunchKernelGGL(add_diag_kernel, dim3((n + 255) / 256), dim3(256), 0, s, A, lda, n, v);
+template <typename R>
+int launch_add_diag(R* A, int64_t lda, int n, double v, hipStream_t s) {
+  hipLaunchKernelGGL(add_diag_kernel<R>, dim3((n + 255) / 256), dim3(256), 0, s, A, lda, n, v);
   GP_HIP(hipGetLastError());
   return 0;
 }
@@ -781,5 +806,34 @@ int launch_fparam(const double* lam_m, const double* lam_var, const double* r, i
   GP_HIP(hipGetLastError());
   return 0;
 }
+
+// ------------------------------------------------------------------ explicit instantiations
+#define GP_INST(R)                                                                                                  \
+  template int launch_localker<R>(const Theta&, const int*, int, int, int, int, R*, int64_t, R*, hipStream_t);      \
+  template int launch_gather<R>(const R*, int64_t, int, const int*, int, int, int, R*, int64_t, R*, int64_t,        \
+                                hipStream_t);                                                                       \
+  template int launch_qvec<R>(const R*, const R*, int64_t, int, int, int, double, R*, R*, hipStream_t);             \
+  template int launch_pack_lower<R>(const R*, int64_t, int, R*, int64_t, int, hipStream_t);                         \
+  template int launch_symmetrize<R>(R*, int64_t, int, hipStream_t);                                                 \
+  template int launch_logdet<R>(const R*, int64_t, int, double*, hipStream_t);                                      \
+  template int launch_frob_lower<R>(const R*, int64_t, int, double*, double*, hipStream_t);                         \
+  template int launch_trmv_lower<R>(const R*, int64_t, int, const R*, R*, hipStream_t);                             \
+  template int launch_trmv_lower_t<R>(const R*, int64_t, int, const R*, R*, double*, hipStream_t);                  \
+  template int launch_dot<R>(const R*, const R*, int, double*, hipStream_t);                                        \
+  template int launch_moments<R>(const R*, const R*, const R*, int64_t, const R*, int64_t, const R*, const R*, int, \
+                                 double, double, R*, R*, R*, R*, double*, hipStream_t);                             \
+  template int launch_adjoint<R>(const R*, const R*, int64_t, const R*, const R*, int, int, R*, double*, double*,   \
+                                 double*, hipStream_t);                                                             \
+  template int launch_adjoint_reduce<R>(const double*, const double*, const double*, int, int, const R*, const R*,  \
+                                        int, int, R*, double*, double*, hipStream_t);                               \
+  template int launch_rowscale_add<R>(R*, int64_t, const R*, int64_t, const R*, int, int, hipStream_t);             \
+  template int launch_reduce_slices<R, R>(const R*, int64_t, int, R*, int64_t, hipStream_t);                        \
+  template int launch_metric_contract<R>(const Theta&, const int*, int, int, int, const R*, int64_t, const R*,      \
+                                         int64_t, double*, hipStream_t);                                            \
+  template int launch_add_diag<R>(R*, int64_t, int, double, hipStream_t);
+GP_INST(double)
+GP_INST(float)
+#undef GP_INST
+template int launch_reduce_slices<double, float>(const double*, int64_t, int, float*, int64_t, hipStream_t);
 
 }  // namespace gpfit

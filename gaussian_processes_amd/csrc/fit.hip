@@ -71,7 +71,8 @@ ProfScope::~ProfScope() {
 }
 
 // flops actually executed by one GEMM launch (whole 128-tiles over each tile's k range)
-double gemm_flops(const GemmArgs& g) {
+template <typename R>
+double gemm_flops(const GemmArgsT<R>& g) {
   const int T = gemm_pick_tile(g);
   const int tm = (g.M + T - 1) / T, tn = (g.N + T - 1) / T, r = TILE / T;
   double steps = 0;
@@ -89,10 +90,11 @@ double gemm_flops(const GemmArgs& g) {
 }
 
 // ------------------------------------------------------------------ GEMM convenience
-static int gemm(hipStream_t s, int a_kmajor, int b_kmajor, int M, int N, int K, double alpha, const double* A,
-                int64_t lda, const double* B, int64_t ldb, double beta, double* C, int64_t ldc, int out_lower,
-                int a_tri, int b_tri, int reverse = 0, int ws = 0) {
-  GemmArgs g{};
+template <typename R>
+static int gemm(hipStream_t s, int a_kmajor, int b_kmajor, int M, int N, int K, double alpha, const R* A,
+                int64_t lda, const R* B, int64_t ldb, double beta, R* C, int64_t ldc, int out_lower, int a_tri,
+                int b_tri, int reverse = 0, int ws = 0) {
+  GemmArgsT<R> g{};
   g.A = A; g.B = B; g.C = C;
   g.lda = lda; g.ldb = ldb; g.ldc = ldc;
   g.M = M; g.N = N; g.K = K;
@@ -112,9 +114,10 @@ static int gemm(hipStream_t s, int a_kmajor, int b_kmajor, int M, int N, int K, 
   } while (0)
 
 // ------------------------------------------------------------------ recursive Cholesky (+ inverse)
-int potrf_rec(const CholBufs& B, int r0, int n, bool need_inv, hipStream_t s) {
+template <typename R>
+int potrf_rec(const CholBufsT<R>& B, int r0, int n, bool need_inv, hipStream_t s) {
   const int64_t ld = B.ld;
-  auto at = [&](double* base, int r, int c) { return base + (int64_t)r * ld + c; };
+  auto at = [&](R* base, int r, int c) { return base + (int64_t)r * ld + c; };
   if (n == TILE) {
     ProfScope ps(s, 0.0, 1);
     return launch_chol_leaf(at(B.A, r0, r0), ld, at(B.L, r0, r0), ld, at(B.Li, r0, r0), ld, B.info, r0, s);
@@ -122,19 +125,22 @@ int potrf_rec(const CholBufs& B, int r0, int n, bool need_inv, hipStream_t s) {
   const int k = n / TILE;
   const int n1 = ((k + 1) / 2) * TILE, n2 = n - n1;
   const int r1 = r0 + n1;
-  GP_TRY(potrf_rec(B, r0, n1, true, s));
+  GP_TRY(potrf_rec<R>(B, r0, n1, true, s));
   // L21 = A21 * L11^-T       (trsm as a GEMM against the explicit inverse; op(B) = Li11^T is upper)
-  GP_TRY(gemm(s, 0, 0, n2, n1, n1, 1.0, at(B.A, r1, r0), ld, at(B.Li, r0, r0), ld, 0.0, at(B.L, r1, r0), ld, 0, 0, 2, /*walk=*/3, B.ws));
+  GP_TRY(gemm<R>(s, 0, 0, n2, n1, n1, 1.0, at(B.A, r1, r0), ld, at(B.Li, r0, r0), ld, 0.0, at(B.L, r1, r0), ld, 0, 0, 2, /*walk=*/3, B.ws));
   // A22 -= L21 L21^T          (syrk, lower tiles only)
-  GP_TRY(gemm(s, 0, 0, n2, n2, n1, -1.0, at(B.L, r1, r0), ld, at(B.L, r1, r0), ld, 1.0, at(B.A, r1, r1), ld, 1, 0, 0, 0, B.ws));
-  GP_TRY(potrf_rec(B, r1, n2, need_inv, s));
+  GP_TRY(gemm<R>(s, 0, 0, n2, n2, n1, -1.0, at(B.L, r1, r0), ld, at(B.L, r1, r0), ld, 1.0, at(B.A, r1, r1), ld, 1, 0, 0, 0, B.ws));
+  GP_TRY(potrf_rec<R>(B, r1, n2, need_inv, s));
   if (need_inv) {
     // Li21 = -Li22 * (L21 * Li11)
-    GP_TRY(gemm(s, 0, 1, n2, n1, n1, 1.0, at(B.L, r1, r0), ld, at(B.Li, r0, r0), ld, 0.0, at(B.Tmp, r1, r0), ld, 0, 0, 1, /*walk=*/2, B.ws));
-    GP_TRY(gemm(s, 0, 1, n2, n1, n2, -1.0, at(B.Li, r1, r1), ld, at(B.Tmp, r1, r0), ld, 0.0, at(B.Li, r1, r0), ld, 0, 1, 0, /*walk=*/1, B.ws));
+    GP_TRY(gemm<R>(s, 0, 1, n2, n1, n1, 1.0, at(B.L, r1, r0), ld, at(B.Li, r0, r0), ld, 0.0, at(B.Tmp, r1, r0), ld, 0, 0, 1, /*walk=*/2, B.ws));
+    GP_TRY(gemm<R>(s, 0, 1, n2, n1, n2, -1.0, at(B.Li, r1, r1), ld, at(B.Tmp, r1, r0), ld, 0.0, at(B.Li, r1, r0), ld, 0, 1, 0, /*walk=*/1, B.ws));
   }
   return 0;
 }
+
+template int potrf_rec<double>(const CholBufsT<double>&, int, int, bool, hipStream_t);
+template int potrf_rec<float>(const CholBufsT<float>&, int, int, bool, hipStream_t);
 
 // ------------------------------------------------------------------ host pieces of localker
 static double lin_pm1_host(int i, int n) {
@@ -191,11 +197,207 @@ static int dev_alloc(gpfit_ctx* c, T** p, size_t count) {
   return 0;
 }
 
+// The fused unit of work, templated on the scalar type of the device data: fp64 is the
+// reference's precision (headline); fp32 serves the hyperparameter-grid configuration
+// (BASELINE configs[4]) -- every matrix, factorisation and GEMM in fp32 on v_mfma_f32_16x16x4_f32,
+// scalars and reductions accumulated in fp64.
+template <typename R>
+static int fit_eval_impl(gpfit_ctx* c, void* stream, const double* theta, const double* lower, const double* upper,
+                         int n_rows, int n_cols, const R* X, int64_t ldx, int64_t N, const R* r, const R* m,
+                         const R* V, int64_t ldv, double logA, double lambda0, int want_grad, double* out_host,
+                         R* lam_m_out, R* lam_var_out, R* f_out) {
+  auto RP = [](double* b) { return reinterpret_cast<R*>(b); };  // workspace is allocated for fp64
+  if (!c || !theta || !X || !r || !m || !V || !out_host || N <= 0) {
+    set_error("gpfit_fit_eval: bad argument");
+    return -3;
+  }
+  const double inf = std::numeric_limits<double>::infinity();
+  if (lower && upper && check_limits(theta, lower, upper) != 0) {
+    // utils.py:2020-2028: out-of-box theta -> infinite loss and infinite gradients
+    out_host[0] = inf;
+    out_host[1] = out_host[2] = std::numeric_limits<double>::quiet_NaN();
+    for (int i = 0; i < 6; ++i) out_host[3 + i] = inf;
+    return -2;
+  }
+  hipStream_t s = (hipStream_t)stream, sa = c->aux;
+  if (getenv("GPFIT_SINGLE_STREAM")) sa = s;
+  const int n = (int)N, np = (int)round_up(N, TILE);
+  const int dfull = n_rows * n_cols;
+  if (np > c->np_cap || dfull > c->dfull_cap) {
+    set_error("gpfit_fit_eval: problem larger than the context capacity");
+    return -3;
+  }
+  const int d = compute_mask(theta, n_rows, n_cols, nullptr, c->pix_host);
+  const int dp = (int)round_up(d, 32);
+  if (d <= 0 || dp > c->dp_cap) {
+    set_error("gpfit_fit_eval: masked pixel count is zero or exceeds the context capacity");
+    return -3;
+  }
+  const Theta th = make_theta(theta);
+  const double s0sq = th.sigma0 * th.sigma0;
+  const double A = std::exp(logA);
+  const int64_t ld = np;
+  c->cur_n = n; c->cur_np = np; c->cur_d = d; c->cur_dp = dp;
+
+  const auto t_host0 = std::chrono::steady_clock::now();
+  prof_begin(c);
+  struct ProfGuard { gpfit_ctx* c; ~ProfGuard() { prof_end(c); } } prof_guard{c};
+  GP_HIP(hipMemsetAsync(c->info, 0, 4 * sizeof(int), s));
+  GP_HIP(hipMemcpyAsync(c->pix, c->pix_host, (size_t)d * sizeof(int), hipMemcpyHostToDevice, s));
+  GP_HIP(hipMemsetAsync(RP(c->mpad), 0, (size_t)np * sizeof(R), s));
+  GP_HIP(hipMemcpyAsync(RP(c->mpad), m, (size_t)n * sizeof(R), hipMemcpyDeviceToDevice, s));
+
+  // ---- aux stream: Cholesky of V (only log|V| and L_V are needed; no full inverse).
+  // Opt-in reuse (flag bit 1 of want_grad): the caller promises V is the matrix of the previous
+  // call on this context (V is constant during an M-step, utils.py:2016-2114), so L_V and
+  // log|V| are kept.  bench.py never sets it: the unit of work includes this factorisation.
+  const bool reuse_V = (want_grad & 2) && c->lv_valid && c->lv_n == n && c->lv_bytes == (int)sizeof(R);
+  want_grad &= 1;
+  GP_HIP(hipEventRecord(c->ev_fork, s));
+  GP_HIP(hipStreamWaitEvent(sa, c->ev_fork, 0));
+  if (!reuse_V) {
+    c->lv_valid = false;
+    GP_TRY(launch_pack_lower(V, ldv, n, RP(c->Vbuf), ld, np, sa));
+    CholBufsT<R> bv{RP(c->Vbuf), RP(c->LVbuf), RP(c->LiVbuf), RP(c->TmpV), ld, c->info + 1, 1};
+    GP_TRY(potrf_rec<R>(bv, 0, np, false, sa));
+    GP_TRY(launch_logdet(RP(c->LVbuf), ld, n, c->scal + 40, sa));
+  }
+  GP_HIP(hipEventRecord(c->ev_join, sa));
+
+  // ---- main stream: metric, kernel matrix, moments, Cholesky of K~ with its inverse
+  GP_TRY(launch_localker<R>(th, c->pix, d, dp, n_rows, n_cols, RP(c->Cmat), dp, nullptr, s));
+  GP_TRY(launch_gather(X, ldx, n, c->pix, d, dp, np, RP(c->Xt), ld, RP(c->Xm), dp, s));
+  GP_TRY(gemm<R>(s, 1, 1, dp, np, dp, 1.0, RP(c->Cmat), dp, RP(c->Xt), ld, 0.0, RP(c->XCt), ld, 0, 0, 0));
+  GP_TRY(launch_qvec(RP(c->Xt), RP(c->XCt), ld, dp, n, np, s0sq, RP(c->Kvec), RP(c->q), s));
+  {
+    GramArgsT<R> g{};
+    g.XCt = RP(c->XCt); g.Xt = RP(c->Xt); g.q1 = RP(c->q); g.q2 = RP(c->q); g.Kout = RP(c->Kbuf); g.Cos = RP(c->Cos);
+    g.ld1 = ld; g.ld2 = ld; g.ldk = ld; g.np1 = np; g.np2 = np; g.nv1 = n; g.nv2 = n; g.Kd = dp;
+    g.s0sq = s0sq; g.lower = 1; g.pad_identity = 1;
+    ProfScope ps(s, (double)np * (np + TILE) * dp, 2);
+    GP_TRY(launch_gram(g, s));
+  }
+  GP_TRY(launch_moments(RP(c->Kvec), RP(c->q), RP(c->Cos), ld, V, ldv, m, r, n, A, lambda0, RP(c->lam_m), RP(c->lam_var), RP(c->fvec),
+                        RP(c->wl), c->scal, s));
+  {
+    CholBufsT<R> bk{RP(c->Kbuf), RP(c->Lbuf), RP(c->Libuf), RP(c->Tmp), ld, c->info + 0};
+    GP_TRY(potrf_rec<R>(bk, 0, np, true, s));
+  }
+  GP_TRY(launch_logdet(RP(c->Lbuf), ld, n, c->scal + 3, s));
+  GP_TRY(launch_trmv_lower(RP(c->Libuf), ld, np, RP(c->mpad), RP(c->yv), s));       // y = L^-1 m
+  GP_TRY(launch_dot(RP(c->yv), RP(c->yv), np, c->scal + 6, s));                  // m^T K~^-1 m
+  GP_TRY(launch_trmv_lower_t(RP(c->Libuf), ld, np, RP(c->yv), RP(c->bv), c->trmv_part, s));  // b = K~^-1 m
+
+  // ---- join: everything that needs both factors
+  GP_HIP(hipStreamWaitEvent(s, c->ev_join, 0));
+  // T = L^-1 L_V (lower x lower -> lower);  tr(K~^-1 V) = ||T||_F^2
+  GP_TRY(gemm<R>(s, 0, 1, np, np, np, 1.0, RP(c->Libuf), ld, RP(c->LVbuf), ld, 0.0, RP(c->Tbuf), ld, 1, 1, 1, /*reverse=*/1));
+  GP_TRY(launch_frob_lower(RP(c->Tbuf), ld, np, c->scal + 5, c->frob_part, s));
+
+  if (want_grad) {
+    // W = 1/2 (K~^-1 - K~^-1 V K~^-1) = 1/2 Li^T (I - T T^T) Li        (T = L^-1 L_V)
+    //   Q = I - T T^T   lower x upper, lower tiles only          N^3/3
+    //   R = Q Li        symmetric x lower                         N^3
+    //   W = 1/2 Li^T R  upper x dense, lower tiles only          N^3/3
+    GP_TRY(gemm<R>(s, 0, 0, np, np, np, -1.0, RP(c->Tbuf), ld, RP(c->Tbuf), ld, 0.0, RP(c->Wbuf), ld, 1, 1, 2, /*reverse=*/1));
+    GP_TRY(launch_add_diag(RP(c->Wbuf), ld, np, 1.0, s));
+    GP_TRY(launch_symmetrize(RP(c->Wbuf), ld, np, s));
+    GP_TRY(gemm<R>(s, 1, 1, np, np, np, 1.0, RP(c->Wbuf), ld, RP(c->Libuf), ld, 0.0, RP(c->Zbuf), ld, 0, 0, 1, /*walk=*/2));
+    GP_TRY(gemm<R>(s, 1, 1, np, np, np, 0.5, RP(c->Libuf), ld, RP(c->Zbuf), ld, 0.0, RP(c->Wbuf), ld, 1, 2, 0, /*walk=*/1));
+    GP_TRY(launch_adjoint(RP(c->Wbuf), RP(c->Cos), ld, RP(c->bv), RP(c->q), n, np, RP(c->Abuf), c->upart, c->vpart, c->sumA_part, s));
+    const int t64 = np / 64;
+    GP_TRY(launch_adjoint_reduce(c->upart, c->vpart, c->sumA_part, t64, t64 * (t64 + 1) / 2, RP(c->q), RP(c->wl), n, np,
+                                 RP(c->tvec), c->rpad, c->scal + 7, s));
+    // pull the contraction with dK~ back to the d x d metric: M = X^T (Aw + diag t) X
+    GP_TRY(gemm<R>(s, 1, 1, np, dp, np, 1.0, RP(c->Abuf), ld, RP(c->Xm), dp, 0.0, RP(c->Ybuf), dp, 0, 0, 0));
+    GP_TRY(launch_rowscale_add(RP(c->Ybuf), dp, RP(c->Xm), dp, RP(c->tvec), np, dp, s));
+    {
+      GemmArgsT<R> g{};
+      g.A = RP(c->Xm); g.B = RP(c->Ybuf); g.C = RP(c->Mpart);
+      g.lda = dp; g.ldb = dp; g.ldc = dp;
+      g.M = dp; g.N = dp; g.K = np;
+      g.alpha = 1.0; g.beta = 0.0; g.a_kmajor = 1; g.b_kmajor = 1;
+      g.batch = 1; g.split_k = c->split_k_M; g.sC = (int64_t)dp * dp;
+      {
+        ProfScope ps(s, g_prof ? gemm_flops(g) : 0.0, (g_prof && gemm_pick_tile(g) != TILE) ? 3 : 0);
+        GP_TRY(launch_gemm(g, s));
+      }
+      GP_TRY(launch_reduce_slices(RP(c->Mpart), (int64_t)dp * dp, c->split_k_M, RP(c->Mmat), (int64_t)dp * dp, s));
+    }
+    GP_TRY(launch_metric_contract(th, c->pix, d, n_rows, n_cols, RP(c->Cmat), dp, RP(c->Mmat), dp, c->scal + 10, s));
+  }
+
+  if (lam_m_out) GP_HIP(hipMemcpyAsync(lam_m_out, RP(c->lam_m), (size_t)n * sizeof(R), hipMemcpyDeviceToDevice, s));
+  if (lam_var_out) GP_HIP(hipMemcpyAsync(lam_var_out, RP(c->lam_var), (size_t)n * sizeof(R), hipMemcpyDeviceToDevice, s));
+  if (f_out) GP_HIP(hipMemcpyAsync(f_out, RP(c->fvec), (size_t)n * sizeof(R), hipMemcpyDeviceToDevice, s));
+  GP_HIP(hipMemcpyAsync(c->scal_host, c->scal, 64 * sizeof(double), hipMemcpyDeviceToHost, s));
+  GP_HIP(hipMemcpyAsync(c->info_host, c->info, 4 * sizeof(int), hipMemcpyDeviceToHost, s));
+  c->last_enqueue_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_host0).count();
+  GP_HIP(hipStreamSynchronize(s));
+
+  const double* sc = c->scal_host;
+  const double loglik = A * sc[0] + lambda0 * sc[1] - sc[2];                   // utils.py:1243
+  // the identity padding of both factors contributes exactly (np - n) to ||L^-1 L_V||_F^2
+  const double trKinvV = sc[5] - (double)(np - n);
+  const double logdetV = sc[40];
+  const double KL = -0.5 * logdetV + 0.5 * sc[3] + 0.5 * sc[6] + 0.5 * trKinvV;  // utils.py:1326
+  out_host[0] = -(loglik - KL);                                                // utils.py:2087-2089
+  out_host[1] = loglik;
+  out_host[2] = KL;
+  if (want_grad) {
+    // d(loss)/d(theta) = dKL - dL (utils.py:2097-2099); metric rows come from the contraction,
+    // the sigma_0 row from the closed form derived from utils.py:996-1004 / 1036.
+    out_host[3] = th.sigma0 * (2.0 * sc[9] + 2.0 * sc[7]) - 2.0 * th.sigma0 * sc[8];
+    out_host[4] = sc[13];  // eps_0x
+    out_host[5] = sc[14];  // eps_0y
+    out_host[6] = sc[11];  // -2log2beta
+    out_host[7] = sc[12];  // -log2rho2
+    out_host[8] = sc[10];  // Amp
+  } else {
+    for (int i = 0; i < 6; ++i) out_host[3 + i] = 0.0;
+  }
+  out_host[9] = sc[3];
+  out_host[10] = logdetV;
+  out_host[11] = trKinvV;
+  out_host[12] = sc[6];
+  out_host[13] = (double)d;
+  out_host[14] = (double)c->info_host[0];
+  out_host[15] = (double)c->info_host[1];
+  if (c->info_host[0] != 0) {
+    set_error("Cholesky of K_tilde failed: non-positive pivot");
+    return c->info_host[0];
+  }
+  if (c->info_host[1] != 0) {
+    set_error("Cholesky of V failed: non-positive pivot");
+    return c->info_host[1];
+  }
+  c->lv_valid = true;
+  c->lv_n = n;
+  c->lv_bytes = (int)sizeof(R);
+  return 0;
+}
+
 }  // namespace gpfit
 
 using namespace gpfit;
 
 extern "C" {
+
+int gpfit_fit_eval(gpfit_ctx* c, void* stream, const double* theta, const double* lower, const double* upper,
+                   int n_rows, int n_cols, const double* X, int64_t ldx, int64_t N, const double* r,
+                   const double* m, const double* V, int64_t ldv, double logA, double lambda0, int want_grad,
+                   double* out_host, double* lam_m_out, double* lam_var_out, double* f_out) {
+  return fit_eval_impl<double>(c, stream, theta, lower, upper, n_rows, n_cols, X, ldx, N, r, m, V, ldv, logA, lambda0,
+                               want_grad, out_host, lam_m_out, lam_var_out, f_out);
+}
+
+int gpfit_fit_eval_f32(gpfit_ctx* c, void* stream, const double* theta, const double* lower, const double* upper,
+                       int n_rows, int n_cols, const float* X, int64_t ldx, int64_t N, const float* r,
+                       const float* m, const float* V, int64_t ldv, double logA, double lambda0, int want_grad,
+                       double* out_host, float* lam_m_out, float* lam_var_out, float* f_out) {
+  return fit_eval_impl<float>(c, stream, theta, lower, upper, n_rows, n_cols, X, ldx, N, r, m, V, ldv, logA, lambda0,
+                              want_grad, out_host, lam_m_out, lam_var_out, f_out);
+}
 
 int gpfit_ctx_create(int device, int64_t n_max, int64_t d_max, int64_t d_full_max, gpfit_ctx** out) {
   if (!out || n_max <= 0 || d_max <= 0) {
@@ -289,177 +491,5 @@ int gpfit_localker_mask(const double* theta, int n_rows, int n_cols, uint8_t* ma
   return 0;
 }
 
-int gpfit_fit_eval(gpfit_ctx* c, void* stream, const double* theta, const double* lower, const double* upper,
-                   int n_rows, int n_cols, const double* X, int64_t ldx, int64_t N, const double* r,
-                   const double* m, const double* V, int64_t ldv, double logA, double lambda0, int want_grad,
-                   double* out_host, double* lam_m_out, double* lam_var_out, double* f_out) {
-  if (!c || !theta || !X || !r || !m || !V || !out_host || N <= 0) {
-    set_error("gpfit_fit_eval: bad argument");
-    return -3;
-  }
-  const double inf = std::numeric_limits<double>::infinity();
-  if (lower && upper && check_limits(theta, lower, upper) != 0) {
-    // utils.py:2020-2028: out-of-box theta -> infinite loss and infinite gradients
-    out_host[0] = inf;
-    out_host[1] = out_host[2] = std::numeric_limits<double>::quiet_NaN();
-    for (int i = 0; i < 6; ++i) out_host[3 + i] = inf;
-    return -2;
-  }
-  hipStream_t s = (hipStream_t)stream, sa = c->aux;
-  if (getenv("GPFIT_SINGLE_STREAM")) sa = s;
-  const int n = (int)N, np = (int)round_up(N, TILE);
-  const int dfull = n_rows * n_cols;
-  if (np > c->np_cap || dfull > c->dfull_cap) {
-    set_error("gpfit_fit_eval: problem larger than the context capacity");
-    return -3;
-  }
-  const int d = compute_mask(theta, n_rows, n_cols, nullptr, c->pix_host);
-  const int dp = (int)round_up(d, 32);
-  if (d <= 0 || dp > c->dp_cap) {
-    set_error("gpfit_fit_eval: masked pixel count is zero or exceeds the context capacity");
-    return -3;
-  }
-  const Theta th = make_theta(theta);
-  const double s0sq = th.sigma0 * th.sigma0;
-  const double A = std::exp(logA);
-  const int64_t ld = np;
-  c->cur_n = n; c->cur_np = np; c->cur_d = d; c->cur_dp = dp;
-
-  const auto t_host0 = std::chrono::steady_clock::now();
-  prof_begin(c);
-  struct ProfGuard { gpfit_ctx* c; ~ProfGuard() { prof_end(c); } } prof_guard{c};
-  GP_HIP(hipMemsetAsync(c->info, 0, 4 * sizeof(int), s));
-  GP_HIP(hipMemcpyAsync(c->pix, c->pix_host, (size_t)d * sizeof(int), hipMemcpyHostToDevice, s));
-  GP_HIP(hipMemsetAsync(c->mpad, 0, (size_t)np * sizeof(double), s));
-  GP_HIP(hipMemcpyAsync(c->mpad, m, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, s));
-
-  // ---- aux stream: Cholesky of V (only log|V| and L_V are needed; no full inverse).
-  // Opt-in reuse (flag bit 1 of want_grad): the caller promises V is the matrix of the previous
-  // call on this context (V is constant during an M-step, utils.py:2016-2114), so L_V and
-  // log|V| are kept.  bench.py never sets it: the unit of work includes this factorisation.
-  const bool reuse_V = (want_grad & 2) && c->lv_valid && c->lv_n == n;
-  want_grad &= 1;
-  GP_HIP(hipEventRecord(c->ev_fork, s));
-  GP_HIP(hipStreamWaitEvent(sa, c->ev_fork, 0));
-  if (!reuse_V) {
-    c->lv_valid = false;
-    GP_TRY(launch_pack_lower(V, ldv, n, c->Vbuf, ld, np, sa));
-    CholBufs bv{c->Vbuf, c->LVbuf, c->LiVbuf, c->TmpV, ld, c->info + 1, 1};
-    GP_TRY(potrf_rec(bv, 0, np, false, sa));
-    GP_TRY(launch_logdet(c->LVbuf, ld, n, c->scal + 40, sa));
-  }
-  GP_HIP(hipEventRecord(c->ev_join, sa));
-
-  // ---- main stream: metric, kernel matrix, moments, Cholesky of K~ with its inverse
-  GP_TRY(launch_localker(th, c->pix, d, dp, n_rows, n_cols, c->Cmat, dp, nullptr, s));
-  GP_TRY(launch_gather(X, ldx, n, c->pix, d, dp, np, c->Xt, ld, c->Xm, dp, s));
-  GP_TRY(gemm(s, 1, 1, dp, np, dp, 1.0, c->Cmat, dp, c->Xt, ld, 0.0, c->XCt, ld, 0, 0, 0));
-  GP_TRY(launch_qvec(c->Xt, c->XCt, ld, dp, n, np, s0sq, c->Kvec, c->q, s));
-  {
-    GramArgs g{};
-    g.XCt = c->XCt; g.Xt = c->Xt; g.q1 = c->q; g.q2 = c->q; g.Kout = c->Kbuf; g.Cos = c->Cos;
-    g.ld1 = ld; g.ld2 = ld; g.ldk = ld; g.np1 = np; g.np2 = np; g.nv1 = n; g.nv2 = n; g.Kd = dp;
-    g.s0sq = s0sq; g.lower = 1; g.pad_identity = 1;
-    ProfScope ps(s, (double)np * (np + TILE) * dp, 2);
-    GP_TRY(launch_gram(g, s));
-  }
-  GP_TRY(launch_moments(c->Kvec, c->q, c->Cos, ld, V, ldv, m, r, n, A, lambda0, c->lam_m, c->lam_var, c->fvec,
-                        c->wl, c->scal, s));
-  {
-    CholBufs bk{c->Kbuf, c->Lbuf, c->Libuf, c->Tmp, ld, c->info + 0};
-    GP_TRY(potrf_rec(bk, 0, np, true, s));
-  }
-  GP_TRY(launch_logdet(c->Lbuf, ld, n, c->scal + 3, s));
-  GP_TRY(launch_trmv_lower(c->Libuf, ld, np, c->mpad, c->yv, s));       // y = L^-1 m
-  GP_TRY(launch_dot(c->yv, c->yv, np, c->scal + 6, s));                  // m^T K~^-1 m
-  GP_TRY(launch_trmv_lower_t(c->Libuf, ld, np, c->yv, c->bv, c->trmv_part, s));  // b = K~^-1 m
-
-  // ---- join: everything that needs both factors
-  GP_HIP(hipStreamWaitEvent(s, c->ev_join, 0));
-  // T = L^-1 L_V (lower x lower -> lower);  tr(K~^-1 V) = ||T||_F^2
-  GP_TRY(gemm(s, 0, 1, np, np, np, 1.0, c->Libuf, ld, c->LVbuf, ld, 0.0, c->Tbuf, ld, 1, 1, 1, /*reverse=*/1));
-  GP_TRY(launch_frob_lower(c->Tbuf, ld, np, c->scal + 5, c->frob_part, s));
-
-  if (want_grad) {
-    // W = 1/2 (K~^-1 - K~^-1 V K~^-1) = 1/2 Li^T (I - T T^T) Li        (T = L^-1 L_V)
-    //   Q = I - T T^T   lower x upper, lower tiles only          N^3/3
-    //   R = Q Li        symmetric x lower                         N^3
-    //   W = 1/2 Li^T R  upper x dense, lower tiles only          N^3/3
-    GP_TRY(gemm(s, 0, 0, np, np, np, -1.0, c->Tbuf, ld, c->Tbuf, ld, 0.0, c->Wbuf, ld, 1, 1, 2, /*reverse=*/1));
-    GP_TRY(launch_add_diag(c->Wbuf, ld, np, 1.0, s));
-    GP_TRY(launch_symmetrize(c->Wbuf, ld, np, s));
-    GP_TRY(gemm(s, 1, 1, np, np, np, 1.0, c->Wbuf, ld, c->Libuf, ld, 0.0, c->Zbuf, ld, 0, 0, 1, /*walk=*/2));
-    GP_TRY(gemm(s, 1, 1, np, np, np, 0.5, c->Libuf, ld, c->Zbuf, ld, 0.0, c->Wbuf, ld, 1, 2, 0, /*walk=*/1));
-    GP_TRY(launch_adjoint(c->Wbuf, c->Cos, ld, c->bv, c->q, n, np, c->Abuf, c->upart, c->vpart, c->sumA_part, s));
-    const int t64 = np / 64;
-    GP_TRY(launch_adjoint_reduce(c->upart, c->vpart, c->sumA_part, t64, t64 * (t64 + 1) / 2, c->q, c->wl, n, np,
-                                 c->tvec, c->scal + 7, s));
-    // pull the contraction with dK~ back to the d x d metric: M = X^T (Aw + diag t) X
-    GP_TRY(gemm(s, 1, 1, np, dp, np, 1.0, c->Abuf, ld, c->Xm, dp, 0.0, c->Ybuf, dp, 0, 0, 0));
-    GP_TRY(launch_rowscale_add(c->Ybuf, dp, c->Xm, dp, c->tvec, np, dp, s));
-    {
-      GemmArgs g{};
-      g.A = c->Xm; g.B = c->Ybuf; g.C = c->Mpart;
-      g.lda = dp; g.ldb = dp; g.ldc = dp;
-      g.M = dp; g.N = dp; g.K = np;
-      g.alpha = 1.0; g.beta = 0.0; g.a_kmajor = 1; g.b_kmajor = 1;
-      g.batch = 1; g.split_k = c->split_k_M; g.sC = (int64_t)dp * dp;
-      {
-        ProfScope ps(s, g_prof ? gemm_flops(g) : 0.0, (g_prof && gemm_pick_tile(g) != TILE) ? 3 : 0);
-        GP_TRY(launch_gemm(g, s));
-      }
-      GP_TRY(launch_reduce_slices(c->Mpart, (int64_t)dp * dp, c->split_k_M, c->Mmat, (int64_t)dp * dp, s));
-    }
-    GP_TRY(launch_metric_contract(th, c->pix, d, n_rows, n_cols, c->Cmat, dp, c->Mmat, dp, c->scal + 10, s));
-  }
-
-  if (lam_m_out) GP_HIP(hipMemcpyAsync(lam_m_out, c->lam_m, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, s));
-  if (lam_var_out) GP_HIP(hipMemcpyAsync(lam_var_out, c->lam_var, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, s));
-  if (f_out) GP_HIP(hipMemcpyAsync(f_out, c->fvec, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, s));
-  GP_HIP(hipMemcpyAsync(c->scal_host, c->scal, 64 * sizeof(double), hipMemcpyDeviceToHost, s));
-  GP_HIP(hipMemcpyAsync(c->info_host, c->info, 4 * sizeof(int), hipMemcpyDeviceToHost, s));
-  c->last_enqueue_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_host0).count();
-  GP_HIP(hipStreamSynchronize(s));
-
-  const double* sc = c->scal_host;
-  const double loglik = A * sc[0] + lambda0 * sc[1] - sc[2];                   // utils.py:1243
-  // the identity padding of both factors contributes exactly (np - n) to ||L^-1 L_V||_F^2
-  const double trKinvV = sc[5] - (double)(np - n);
-  const double logdetV = sc[40];
-  const double KL = -0.5 * logdetV + 0.5 * sc[3] + 0.5 * sc[6] + 0.5 * trKinvV;  // utils.py:1326
-  out_host[0] = -(loglik - KL);                                                // utils.py:2087-2089
-  out_host[1] = loglik;
-  out_host[2] = KL;
-  if (want_grad) {
-    // d(loss)/d(theta) = dKL - dL (utils.py:2097-2099); metric rows come from the contraction,
-    // the sigma_0 row from the closed form derived from utils.py:996-1004 / 1036.
-    out_host[3] = th.sigma0 * (2.0 * sc[9] + 2.0 * sc[7]) - 2.0 * th.sigma0 * sc[8];
-    out_host[4] = sc[13];  // eps_0x
-    out_host[5] = sc[14];  // eps_0y
-    out_host[6] = sc[11];  // -2log2beta
-    out_host[7] = sc[12];  // -log2rho2
-    out_host[8] = sc[10];  // Amp
-  } else {
-    for (int i = 0; i < 6; ++i) out_host[3 + i] = 0.0;
-  }
-  out_host[9] = sc[3];
-  out_host[10] = logdetV;
-  out_host[11] = trKinvV;
-  out_host[12] = sc[6];
-  out_host[13] = (double)d;
-  out_host[14] = (double)c->info_host[0];
-  out_host[15] = (double)c->info_host[1];
-  if (c->info_host[0] != 0) {
-    set_error("Cholesky of K_tilde failed: non-positive pivot");
-    return c->info_host[0];
-  }
-  if (c->info_host[1] != 0) {
-    set_error("Cholesky of V failed: non-positive pivot");
-    return c->info_host[1];
-  }
-  c->lv_valid = true;
-  c->lv_n = n;
-  return 0;
-}
 
 }  // extern "C"

@@ -1,15 +1,16 @@
-// General fp64 MFMA GEMM for gfx950 with per-tile triangular k ranges, lower-only output,
-// batching and split-K.  See common.h for the argument contract.
+// General MFMA GEMM for gfx950 (fp64 and fp32 instances) with per-tile triangular k ranges,
+// lower-only output, batching and split-K.  See common.h for the argument contract.
 #include "gemm_core.h"
 
 #include <algorithm>
 
 namespace gpfit {
 
-template <bool A_KMAJOR, bool B_KMAJOR, bool EDGE, int T>
-__global__ __launch_bounds__(GEMM_THREADS, (T == 128 ? 2 : 4)) void dgemm_mfma_kernel(GemmArgs p, int tiles_n,
-                                                                                      int ntiles) {
-  __shared__ __attribute__((aligned(16))) double smem[4 * KTILE * T];
+template <typename R, bool A_KMAJOR, bool B_KMAJOR, bool EDGE, int T>
+__global__ __launch_bounds__(GEMM_THREADS, (T == 128 ? 2 : 4)) void gemm_mfma_kernel(GemmArgsT<R> p, int tiles_n,
+                                                                                     int ntiles) {
+  constexpr int KT = Real<R>::KT;
+  __shared__ __attribute__((aligned(16))) R smem[4 * KT * T];
 
   // heaviest tiles first: with triangular operands the k range depends on the tile position,
   // so the launcher asks for the walk that starts with the long ones (shorter tail):
@@ -28,44 +29,44 @@ __global__ __launch_bounds__(GEMM_THREADS, (T == 128 ? 2 : 4)) void dgemm_mfma_k
   }
   const int row0 = ti * T, col0 = tj * T;
   const int b = blockIdx.y, z = blockIdx.z;
-  const double* A = p.A + (int64_t)b * p.sA;
-  const double* B = p.B + (int64_t)b * p.sB;
-  double* C = p.C + (int64_t)b * p.sC;
+  const R* A = p.A + (int64_t)b * p.sA;
+  const R* B = p.B + (int64_t)b * p.sB;
+  R* C = p.C + (int64_t)b * p.sC;
 
   int kbeg = 0, kend = p.K;
   if (p.a_tri == 1) kend = min(kend, row0 + T);
   if (p.a_tri == 2) kbeg = max(kbeg, row0);
   if (p.b_tri == 1) kbeg = max(kbeg, col0);
   if (p.b_tri == 2) kend = min(kend, col0 + T);
+  // tri bounds are multiples of T >= 32 = the largest K step, so they stay K-step aligned
   if (p.split_k > 1) {
-    // split the (16-aligned) k range into split_k nearly equal 16-aligned pieces
-    const int steps = max(0, kend - kbeg) / KTILE;
+    const int steps = max(0, kend - kbeg) / KT;
     const int per = (steps + p.split_k - 1) / p.split_k;
     const int s0 = min(steps, z * per), s1 = min(steps, (z + 1) * per);
-    kend = kbeg + s1 * KTILE;
-    kbeg = kbeg + s0 * KTILE;
+    kend = kbeg + s1 * KT;
+    kbeg = kbeg + s0 * KT;
     C += (int64_t)z * p.sC;
   }
 
-  v4d acc[T / 32][T / 32];
+  typename Real<R>::acc_t acc[T / 32][T / 32];
 #pragma unroll
   for (int i = 0; i < T / 32; ++i)
 #pragma unroll
-    for (int j = 0; j < T / 32; ++j) acc[i][j] = v4d{0.0, 0.0, 0.0, 0.0};
+    for (int j = 0; j < T / 32; ++j) acc[i][j] = acc_zero<R>();
 
-  gemm_mainloop<A_KMAJOR, B_KMAJOR, EDGE, T>(A, p.lda, B, p.ldb, p.M, p.N, row0, col0, kbeg, kend, smem, acc);
+  gemm_mainloop<R, A_KMAJOR, B_KMAJOR, EDGE, T>(A, p.lda, B, p.ldb, p.M, p.N, row0, col0, kbeg, kend, smem, acc);
 
-  const double alpha = p.alpha, beta = (p.split_k > 1) ? 0.0 : p.beta;
+  const R alpha = (R)p.alpha, beta = (p.split_k > 1) ? (R)0 : (R)p.beta;
   const int64_t ldc = p.ldc;
   const int M = p.M, N = p.N;
-  if (beta == 0.0) {
-    for_each_acc<T>(acc, row0, col0, [&](int row, int col, double v) {
+  if (beta == (R)0) {
+    for_each_acc<R, T>(acc, row0, col0, [&](int row, int col, R v) {
       if (!EDGE || (row < M && col < N)) C[(int64_t)row * ldc + col] = alpha * v;
     });
   } else {
-    for_each_acc<T>(acc, row0, col0, [&](int row, int col, double v) {
+    for_each_acc<R, T>(acc, row0, col0, [&](int row, int col, R v) {
       if (!EDGE || (row < M && col < N)) {
-        double* c = C + (int64_t)row * ldc + col;
+        R* c = C + (int64_t)row * ldc + col;
         *c = alpha * v + beta * (*c);
       }
     });
@@ -74,7 +75,8 @@ __global__ __launch_bounds__(GEMM_THREADS, (T == 128 ? 2 : 4)) void dgemm_mfma_k
 
 // Tile size: 128 when that already gives the chip >= 1.5 waves of blocks, otherwise 64 / 32 so
 // the small panels near the leaves of the recursion are not serialised on a handful of CUs.
-int gemm_pick_tile(const GemmArgs& a) {
+template <typename R>
+int gemm_pick_tile(const GemmArgsT<R>& a) {
   if (a.tile == 128 || a.tile == 64 || a.tile == 32) return a.tile;
   auto ntiles = [&](int T) {
     const long tm = (a.M + T - 1) / T, tn = (a.N + T - 1) / T;
@@ -87,15 +89,15 @@ int gemm_pick_tile(const GemmArgs& a) {
   return (a.M <= 1024 && a.N <= 1024) ? 32 : 64;
 }
 
-template <int T>
-static void launch_T(const GemmArgs& p, hipStream_t s) {
+template <typename R, int T>
+static void launch_T(const GemmArgsT<R>& p, hipStream_t s) {
   const int tm = (p.M + T - 1) / T, tn = (p.N + T - 1) / T;
   const int tiles = p.out_lower ? lower_tile_count((p.M + TILE - 1) / TILE, TILE / T) : tm * tn;
   const bool edge = (p.M % T) || (p.N % T) || (p.out_lower && (p.M % TILE));
   dim3 grid(p.tile_limit > 0 ? std::min(p.tile_limit, tiles) : tiles, p.batch, p.split_k > 1 ? p.split_k : 1);
   dim3 block(GEMM_THREADS);
 #define GP_LAUNCH(AK, BK, ED) \
-  hipLaunchKernelGGL((dgemm_mfma_kernel<AK, BK, ED, T>), grid, block, 0, s, p, tn, tiles)
+  hipLaunchKernelGGL((gemm_mfma_kernel<R, AK, BK, ED, T>), grid, block, 0, s, p, tn, tiles)
   const int sel = (p.a_kmajor ? 4 : 0) | (p.b_kmajor ? 2 : 0) | (edge ? 1 : 0);
   switch (sel) {
     case 0: GP_LAUNCH(false, false, false); break;
@@ -110,7 +112,8 @@ static void launch_T(const GemmArgs& p, hipStream_t s) {
 #undef GP_LAUNCH
 }
 
-int launch_gemm(const GemmArgs& a, hipStream_t s) {
+template <typename R>
+int launch_gemm(const GemmArgsT<R>& a, hipStream_t s) {
   if (a.M <= 0 || a.N <= 0) return 0;
   if (a.tile_limit == 0 && gemm_pick_tile(a) == TILE && a.batch <= 1) {
     const int rc = launch_gemm_streamk(a, s);  // large launches: balanced schedules (gemm_streamk.hip)
@@ -119,27 +122,36 @@ int launch_gemm(const GemmArgs& a, hipStream_t s) {
   return launch_gemm_plain(a, s);
 }
 
-int launch_gemm_plain(const GemmArgs& a, hipStream_t s) {
+template <typename R>
+int launch_gemm_plain(const GemmArgsT<R>& a, hipStream_t s) {
   if (a.M <= 0 || a.N <= 0) return 0;
-  // odd M/N are fine for the stores; k-major operands are then read one element past M/N,
-  // which internal callers cover with zero padding (the public gpfit_dgemm insists on even).
-  if (a.K % KTILE != 0 || (a.lda & 1) || (a.ldb & 1)) {
-    set_error("launch_gemm: K must be a multiple of 16 and lda, ldb even");
+  // odd M/N are fine for the stores; k-major operands are then read up to one 16-byte chunk past
+  // M/N, which internal callers cover with zero padding (the public gpfit_dgemm insists on even).
+  constexpr int EPC = 16 / (int)sizeof(R);
+  if (a.K % ktile_of<R>() != 0 || (a.lda % EPC) || (a.ldb % EPC)) {
+    set_error("launch_gemm: K must be a multiple of the K step and lda, ldb multiples of 16 bytes");
     return -3;
   }
   if (a.out_lower && a.M != a.N) {
     set_error("launch_gemm: out_lower needs a square output");
     return -3;
   }
-  GemmArgs p = a;
+  GemmArgsT<R> p = a;
   if (p.batch <= 0) p.batch = 1;
   switch (gemm_pick_tile(p)) {
-    case 128: launch_T<128>(p, s); break;
-    case 64: launch_T<64>(p, s); break;
-    default: launch_T<32>(p, s); break;
+    case 128: launch_T<R, 128>(p, s); break;
+    case 64: launch_T<R, 64>(p, s); break;
+    default: launch_T<R, 32>(p, s); break;
   }
   GP_HIP(hipGetLastError());
   return 0;
 }
+
+template int launch_gemm<double>(const GemmArgsT<double>&, hipStream_t);
+template int launch_gemm<float>(const GemmArgsT<float>&, hipStream_t);
+template int launch_gemm_plain<double>(const GemmArgsT<double>&, hipStream_t);
+template int launch_gemm_plain<float>(const GemmArgsT<float>&, hipStream_t);
+template int gemm_pick_tile<double>(const GemmArgsT<double>&);
+template int gemm_pick_tile<float>(const GemmArgsT<float>&);
 
 }  // namespace gpfit

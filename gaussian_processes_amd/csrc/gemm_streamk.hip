@@ -40,24 +40,26 @@ struct SkPlan {
   int nfix = 0;
 };
 
+template <typename R>
 struct SkParams {
-  const double* A;
-  const double* B;
-  double* C;
+  const R* A;
+  const R* B;
+  R* C;
   int64_t lda, ldb, ldc;
   int M, N;
   double alpha, beta;
   const SkTile* tiles;
   int ntiles;
   int total, per_block;
-  double* partial;
+  R* partial;
 };
 
 constexpr int SK_SLOTS = 512;  // resident workgroups: 256 CUs x 2 (244 VGPRs, 64 KiB LDS each)
 
-template <bool A_KMAJOR, bool B_KMAJOR>
-__global__ __launch_bounds__(GEMM_THREADS, 2) void dgemm_streamk_kernel(SkParams p) {
-  __shared__ __attribute__((aligned(16))) double smem[4 * KTILE * TILE];
+template <typename R, bool A_KMAJOR, bool B_KMAJOR>
+__global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_streamk_kernel(SkParams<R> p) {
+  constexpr int KT = Real<R>::KT;
+  __shared__ __attribute__((aligned(16))) R smem[4 * KT * TILE];
   int it = (int)blockIdx.x * p.per_block;
   const int it_end = min(p.total, it + p.per_block);
   if (it >= it_end) return;
@@ -72,30 +74,30 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void dgemm_streamk_kernel(SkParams
     const SkTile tl = p.tiles[t];
     const int tbeg = tl.prefix, tend = tbeg + tl.ksteps;
     const int s1 = min(it_end, tend);
-    const int kb = tl.kbeg + (it - tbeg) * KTILE, ke = tl.kbeg + (s1 - tbeg) * KTILE;
-    v4d acc[4][4];
+    const int kb = tl.kbeg + (it - tbeg) * KT, ke = tl.kbeg + (s1 - tbeg) * KT;
+    typename Real<R>::acc_t acc[4][4];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) acc[i][j] = v4d{0.0, 0.0, 0.0, 0.0};
-    gemm_mainloop<A_KMAJOR, B_KMAJOR, false, TILE>(p.A, p.lda, p.B, p.ldb, p.M, p.N, tl.row0, tl.col0, kb, ke,
+      for (int j = 0; j < 4; ++j) acc[i][j] = acc_zero<R>();
+    gemm_mainloop<R, A_KMAJOR, B_KMAJOR, false, TILE>(p.A, p.lda, p.B, p.ldb, p.M, p.N, tl.row0, tl.col0, kb, ke,
                                                    smem, acc);
     if (it == tbeg && s1 == tend) {
-      double* __restrict__ C = p.C;
+      R* __restrict__ C = p.C;
       const int64_t ldc = p.ldc;
-      const double alpha = p.alpha, beta = p.beta;
-      if (beta == 0.0) {
-        for_each_acc<TILE>(acc, tl.row0, tl.col0,
-                           [&](int row, int col, double v) { C[(int64_t)row * ldc + col] = alpha * v; });
+      const R alpha = (R)p.alpha, beta = (R)p.beta;
+      if (beta == (R)0) {
+        for_each_acc<R, TILE>(acc, tl.row0, tl.col0,
+                              [&](int row, int col, R v) { C[(int64_t)row * ldc + col] = alpha * v; });
       } else {
-        for_each_acc<TILE>(acc, tl.row0, tl.col0, [&](int row, int col, double v) {
-          double* c = C + (int64_t)row * ldc + col;
+        for_each_acc<R, TILE>(acc, tl.row0, tl.col0, [&](int row, int col, R v) {
+          R* c = C + (int64_t)row * ldc + col;
           *c = alpha * v + beta * (*c);
         });
       }
     } else {
-      double* __restrict__ P = p.partial + ((int64_t)2 * blockIdx.x + (nseg > 0 ? 1 : 0)) * (TILE * TILE);
-      for_each_acc<TILE>(acc, 0, 0, [&](int row, int col, double v) { P[row * TILE + col] = v; });
+      R* __restrict__ P = p.partial + ((int64_t)2 * blockIdx.x + (nseg > 0 ? 1 : 0)) * (TILE * TILE);
+      for_each_acc<R, TILE>(acc, 0, 0, [&](int row, int col, R v) { P[row * TILE + col] = v; });
     }
     ++nseg;
     it = s1;
@@ -104,33 +106,30 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void dgemm_streamk_kernel(SkParams
 }
 
 // C tile = alpha * (sum of its partial slots, in plan order) + beta * C
-__global__ __launch_bounds__(256) void streamk_fixup_kernel(SkParams p, const int* __restrict__ fix_tile,
+template <typename R>
+__global__ __launch_bounds__(256) void streamk_fixup_kernel(SkParams<R> p, const int* __restrict__ fix_tile,
                                                             const int* __restrict__ fix_ptr,
                                                             const int* __restrict__ fix_slot) {
   const SkTile tl = p.tiles[fix_tile[blockIdx.x]];
   const int s0 = fix_ptr[blockIdx.x], s1 = fix_ptr[blockIdx.x + 1];
-  for (int e = threadIdx.x; e < TILE * TILE / 2; e += blockDim.x) {
-    const int r = e >> 6, c = (e & 63) * 2;
-    v2d sum = v2d{0.0, 0.0};
-    for (int s = s0; s < s1; ++s)
-      sum += *reinterpret_cast<const v2d*>(p.partial + (int64_t)fix_slot[s] * (TILE * TILE) + r * TILE + c);
-    double* cp = p.C + (int64_t)(tl.row0 + r) * p.ldc + tl.col0 + c;
-    if (p.beta == 0.0) {
-      cp[0] = p.alpha * sum.x;
-      cp[1] = p.alpha * sum.y;
-    } else {
-      cp[0] = p.alpha * sum.x + p.beta * cp[0];
-      cp[1] = p.alpha * sum.y + p.beta * cp[1];
-    }
+  const R alpha = (R)p.alpha, beta = (R)p.beta;
+  for (int e = threadIdx.x; e < TILE * TILE; e += blockDim.x) {
+    const int r = e >> 7, c = e & 127;
+    R sum = 0;
+    for (int s = s0; s < s1; ++s) sum += p.partial[(int64_t)fix_slot[s] * (TILE * TILE) + r * TILE + c];
+    R* cp = p.C + (int64_t)(tl.row0 + r) * p.ldc + tl.col0 + c;
+    *cp = (beta == (R)0) ? alpha * sum : alpha * sum + beta * (*cp);
   }
 }
 
-using SkKey = std::tuple<int, int, int, int, int, int, int>;
+using SkKey = std::tuple<int, int, int, int, int, int, int, int>;  // ..., K step
 static std::map<SkKey, SkPlan> g_plans;
 static std::mutex g_plan_mutex;
-static double* g_workspace[2] = {nullptr, nullptr};
+static void* g_workspace[2] = {nullptr, nullptr};  // sized for fp64, shared by the fp32 instances
 
-static int build_plan(const GemmArgs& a, int first, SkPlan& plan) {
+template <typename R>
+static int build_plan(const GemmArgsT<R>& a, int first, SkPlan& plan) {
+  constexpr int KT = 128 / (int)sizeof(R);
   const int tm = a.M / TILE, tn = a.N / TILE;
   const int all_tiles = a.out_lower ? tm * (tm + 1) / 2 : tm * tn;
   const int ntiles = all_tiles - first;
@@ -148,7 +147,7 @@ static int build_plan(const GemmArgs& a, int first, SkPlan& plan) {
     if (a.a_tri == 2) kb = std::max(kb, ti * TILE);
     if (a.b_tri == 1) kb = std::max(kb, tj * TILE);
     if (a.b_tri == 2) ke = std::min(ke, tj * TILE + TILE);
-    const int ks = std::max(0, ke - kb) / KTILE;
+    const int ks = std::max(0, ke - kb) / KT;
     if (ks == 0) return 1;  // empty tiles would need a beta-only pass: leave those launches to gemm.hip
     tiles.push_back(SkTile{ti * TILE, tj * TILE, kb, ks, (int)prefix});
     prefix += ks;
@@ -205,7 +204,8 @@ static int build_plan(const GemmArgs& a, int first, SkPlan& plan) {
 //    rounds stay data-parallel -- workgroups that start together walk k in lock step and share
 //    operand panels in L2, which stream-K's staggered shares give up -- and only the tail tiles
 //    are cut along k over the whole chip.
-int launch_gemm_streamk(const GemmArgs& a, hipStream_t s) {
+template <typename R>
+int launch_gemm_streamk(const GemmArgsT<R>& a, hipStream_t s) {
   static const bool disabled = getenv("GPFIT_NO_STREAMK") != nullptr;
   if (disabled) return 1;
   if ((a.M % TILE) || (a.N % TILE) || a.split_k > 1 || a.batch > 1 || (a.tile && a.tile != TILE)) return 1;
@@ -224,7 +224,7 @@ int launch_gemm_streamk(const GemmArgs& a, hipStream_t s) {
   SkPlan plan;
   {
     std::lock_guard<std::mutex> lock(g_plan_mutex);
-    const SkKey key{a.M, a.N, a.K, a.out_lower, a.a_tri, a.b_tri, (a.reverse & 3) | (first ? 4 : 0)};
+    const SkKey key{a.M, a.N, a.K, a.out_lower, a.a_tri, a.b_tri, (a.reverse & 3) | (first ? 4 : 0), (int)sizeof(R)};
     auto itp = g_plans.find(key);
     if (itp == g_plans.end()) {
       SkPlan np;
@@ -233,32 +233,35 @@ int launch_gemm_streamk(const GemmArgs& a, hipStream_t s) {
       itp = g_plans.emplace(key, np).first;
     }
     plan = itp->second;
-    if (!g_workspace[ws]) GP_HIP(hipMalloc((void**)&g_workspace[ws], (size_t)2 * SK_SLOTS * TILE * TILE * sizeof(double)));
+    if (!g_workspace[ws]) GP_HIP(hipMalloc(&g_workspace[ws], (size_t)2 * SK_SLOTS * TILE * TILE * sizeof(double)));
   }
   if (first > 0) {  // the full rounds, data-parallel
-    GemmArgs head = a;
+    GemmArgsT<R> head = a;
     head.tile = TILE;
     head.tile_limit = first;
     const int rc = launch_gemm_plain(head, s);
     if (rc != 0) return rc;
   }
-  SkParams p{};
+  SkParams<R> p{};
   p.A = a.A; p.B = a.B; p.C = a.C; p.lda = a.lda; p.ldb = a.ldb; p.ldc = a.ldc; p.M = a.M; p.N = a.N;
   p.alpha = a.alpha; p.beta = a.beta; p.tiles = plan.tiles; p.ntiles = plan.ntiles; p.total = plan.total;
-  p.per_block = plan.per_block; p.partial = g_workspace[ws];
+  p.per_block = plan.per_block; p.partial = (R*)g_workspace[ws];
   dim3 grid(plan.blocks), block(GEMM_THREADS);
   const int sel = (a.a_kmajor ? 2 : 0) | (a.b_kmajor ? 1 : 0);
   switch (sel) {
-    case 0: hipLaunchKernelGGL((dgemm_streamk_kernel<false, false>), grid, block, 0, s, p); break;
-    case 1: hipLaunchKernelGGL((dgemm_streamk_kernel<false, true>), grid, block, 0, s, p); break;
-    case 2: hipLaunchKernelGGL((dgemm_streamk_kernel<true, false>), grid, block, 0, s, p); break;
-    case 3: hipLaunchKernelGGL((dgemm_streamk_kernel<true, true>), grid, block, 0, s, p); break;
+    case 0: hipLaunchKernelGGL((gemm_streamk_kernel<R, false, false>), grid, block, 0, s, p); break;
+    case 1: hipLaunchKernelGGL((gemm_streamk_kernel<R, false, true>), grid, block, 0, s, p); break;
+    case 2: hipLaunchKernelGGL((gemm_streamk_kernel<R, true, false>), grid, block, 0, s, p); break;
+    case 3: hipLaunchKernelGGL((gemm_streamk_kernel<R, true, true>), grid, block, 0, s, p); break;
   }
   if (plan.nfix)
-    hipLaunchKernelGGL(streamk_fixup_kernel, dim3(plan.nfix), dim3(256), 0, s, p, plan.fix_tile, plan.fix_ptr,
+    hipLaunchKernelGGL(streamk_fixup_kernel<R>, dim3(plan.nfix), dim3(256), 0, s, p, plan.fix_tile, plan.fix_ptr,
                        plan.fix_slot);
   GP_HIP(hipGetLastError());
   return 0;
 }
+
+template int launch_gemm_streamk<double>(const GemmArgsT<double>&, hipStream_t);
+template int launch_gemm_streamk<float>(const GemmArgsT<float>&, hipStream_t);
 
 }  // namespace gpfit

@@ -11,12 +11,14 @@
 // symmetric N x N matrix of the library: the lower triangle (i >= j) is canonical; the strict
 // upper part of a diagonal tile is written but never read, tiles above the diagonal are not
 // written at all (gpfit_symmetrize mirrors when a caller wants the full matrix).
+// Instantiated for fp64 (the reference's precision) and fp32 (theta-grid configuration).
 #include "gemm_core.h"
 
 namespace gpfit {
 
-__global__ __launch_bounds__(GEMM_THREADS, 2) void gram_acos_kernel(GramArgs p, int tiles_n) {
-  __shared__ __attribute__((aligned(16))) double smem[4 * KTILE * TILE];
+template <typename R>
+__global__ __launch_bounds__(GEMM_THREADS, 2) void gram_acos_kernel(GramArgsT<R> p, int tiles_n) {
+  __shared__ __attribute__((aligned(16))) R smem[4 * Real<R>::KT * TILE];
   int ti, tj;
   if (p.lower) {
     tri_tile(blockIdx.x, ti, tj);
@@ -25,50 +27,53 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gram_acos_kernel(GramArgs p, 
     tj = blockIdx.x % tiles_n;
   }
   const int row0 = ti * TILE, col0 = tj * TILE;
-  v4d acc[4][4];
+  typename Real<R>::acc_t acc[4][4];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = v4d{0.0, 0.0, 0.0, 0.0};
+    for (int j = 0; j < 4; ++j) acc[i][j] = acc_zero<R>();
 
   // operands are zero-padded to whole tiles: no edge predication on the loads
-  gemm_mainloop<true, true, false, TILE>(p.XCt, p.ld1, p.Xt, p.ld2, p.np1, p.np2, row0, col0, 0, p.Kd, smem, acc);
+  gemm_mainloop<R, true, true, false, TILE>(p.XCt, p.ld1, p.Xt, p.ld2, p.np1, p.np2, row0, col0, 0, p.Kd, smem, acc);
 
   const int nv1 = p.nv1, nv2 = p.nv2;
   const bool pad_id = p.pad_identity != 0;
   const int64_t ldk = p.ldk;
   const int64_t ldcos = p.ldcos ? p.ldcos : p.ldk;
-  const double s0sq = p.s0sq;
-  const double* __restrict__ q1 = p.q1;
-  const double* __restrict__ q2 = p.q2;
-  double* __restrict__ Ko = p.Kout;
-  double* __restrict__ Co = p.Cos;
+  const R s0sq = (R)p.s0sq;
+  const R pi32 = (R)PI32;
+  const R* __restrict__ q1 = p.q1;
+  const R* __restrict__ q2 = p.q2;
+  R* __restrict__ Ko = p.Kout;
+  R* __restrict__ Co = p.Cos;
 
-  for_each_acc<TILE>(acc, row0, col0, [&](int row, int col, double g) {
+  for_each_acc<R, TILE>(acc, row0, col0, [&](int row, int col, R g) {
     const int64_t o = (int64_t)row * ldk + col;
     const int64_t oc = (int64_t)row * ldcos + col;
     if (row >= nv1 || col >= nv2) {
       // padding: identity on the diagonal so the padded matrix factorises as [L 0; 0 I]
       if (pad_id) {
-        Ko[o] = (row == col) ? 1.0 : 0.0;
-        if (Co) Co[oc] = 0.0;
+        Ko[o] = (row == col) ? (R)1 : (R)0;
+        if (Co) Co[oc] = (R)0;
       }
       return;
     }
-    const double qq = q1[row] * q2[col];
-    double c = (g + s0sq) / (qq + 1e-7);
-    c = fmin(1.0, fmax(-1.0, c));
-    const double delta = acos(c);
-    const double J = (sqrt(1.0 - c * c) + PI32 * c - delta * c) / PI32;
+    const R qq = q1[row] * q2[col];
+    R c = (g + s0sq) / (qq + (R)1e-7);
+    c = fmin((R)1, fmax((R)-1, c));
+    const R delta = acos(c);
+    const R J = (sqrt((R)1 - c * c) + pi32 * c - delta * c) / pi32;
     Ko[o] = qq * J;
     if (Co) Co[oc] = c;
   });
 }
 
-int launch_gram(const GramArgs& a, hipStream_t s) {
+template <typename R>
+int launch_gram(const GramArgsT<R>& a, hipStream_t s) {
   if (a.nv1 <= 0 || a.nv2 <= 0) return 0;
-  if (a.Kd % KTILE != 0 || (a.np1 % TILE) || (a.np2 % TILE) || (a.ld1 & 1) || (a.ld2 & 1)) {
-    set_error("launch_gram: Kd must be a multiple of 16, np1/np2 multiples of 128, ld1/ld2 even");
+  constexpr int EPC = 16 / (int)sizeof(R);
+  if (a.Kd % ktile_of<R>() != 0 || (a.np1 % TILE) || (a.np2 % TILE) || (a.ld1 % EPC) || (a.ld2 % EPC)) {
+    set_error("launch_gram: Kd must be a multiple of the K step, np1/np2 multiples of 128, ld1/ld2 of 16 bytes");
     return -3;
   }
   if (a.lower && a.np1 != a.np2) {
@@ -79,9 +84,12 @@ int launch_gram(const GramArgs& a, hipStream_t s) {
   const int tm = (a.pad_identity ? a.np1 : (int)round_up(a.nv1, TILE)) / TILE;
   const int tn = (a.pad_identity ? a.np2 : (int)round_up(a.nv2, TILE)) / TILE;
   const int tiles = a.lower ? tm * (tm + 1) / 2 : tm * tn;
-  hipLaunchKernelGGL(gram_acos_kernel, dim3(tiles), dim3(GEMM_THREADS), 0, s, a, tn);
+  hipLaunchKernelGGL(gram_acos_kernel<R>, dim3(tiles), dim3(GEMM_THREADS), 0, s, a, tn);
   GP_HIP(hipGetLastError());
   return 0;
 }
+
+template int launch_gram<double>(const GramArgsT<double>&, hipStream_t);
+template int launch_gram<float>(const GramArgsT<float>&, hipStream_t);
 
 }  // namespace gpfit

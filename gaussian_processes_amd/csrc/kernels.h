@@ -11,69 +11,78 @@ struct Theta {
 };
 
 // ---- chol_leaf.hip
-int launch_chol_leaf(const double* A, int64_t lda, double* L, int64_t ldl, double* Linv, int64_t ldi,
-                     int* info, int info_base, hipStream_t s);
+template <typename R>
+int launch_chol_leaf(const R* A, int64_t lda, R* L, int64_t ldl, R* Linv, int64_t ldi, int* info, int info_base,
+                     hipStream_t s);
 
-// ---- elementwise.hip
+// ---- elementwise.hip  (templated on the scalar type R = double | float; reductions are always
+//      accumulated and returned in fp64)
 // Spatial metric C (utils.py:861-914) over the masked pixels pix[d] of an n_rows x n_cols
 // grid.  C is written zero-padded to [dp][ldc]; dC (optional) as 5 dense [d][d] matrices in
 // the order Amp, -2log2beta, -log2rho2, eps_0x, eps_0y (the reference's dict order, :910).
-int launch_localker(const Theta& th, const int* pix, int d, int dp, int n_rows, int n_cols, double* C,
-                    int64_t ldc, double* dC, hipStream_t s);
-
+template <typename R>
+int launch_localker(const Theta& th, const int* pix, int d, int dp, int n_rows, int n_cols, R* C, int64_t ldc,
+                    R* dC, hipStream_t s);
 // Xt[k][n] = X[n][pix[k]] (k-major, zero padded to [dp][ldt]) and optionally the row-major
 // masked copy Xm[n][k] ([np][ldm], zero padded).
-int launch_gather(const double* X, int64_t ldx, int n, const int* pix, int d, int dp, int np, double* Xt,
-                  int64_t ldt, double* Xm, int64_t ldm, hipStream_t s);
-
+template <typename R>
+int launch_gather(const R* X, int64_t ldx, int n, const int* pix, int d, int dp, int np, R* Xt, int64_t ldt, R* Xm,
+                  int64_t ldm, hipStream_t s);
 // h[n] = sum_k Xt[k][n]*XCt[k][n];  Kvec = h + s0^2;  q = sqrt(Kvec)  (q = 1 on padding)
-int launch_qvec(const double* Xt, const double* XCt, int64_t ld, int dp, int n, int np, double s0sq,
-                double* Kvec, double* q, hipStream_t s);
-
+template <typename R>
+int launch_qvec(const R* Xt, const R* XCt, int64_t ld, int dp, int n, int np, double s0sq, R* Kvec, R* q,
+                hipStream_t s);
 // dst lower tiles <- src (n x n, ld lds) with identity padding up to np.
-int launch_pack_lower(const double* src, int64_t lds, int n, double* dst, int64_t ldd, int np, hipStream_t s);
+template <typename R>
+int launch_pack_lower(const R* src, int64_t lds, int n, R* dst, int64_t ldd, int np, hipStream_t s);
 // mirror the lower triangle of an n x n matrix into its upper triangle (in place)
-int launch_symmetrize(double* A, int64_t lda, int n, hipStream_t s);
+template <typename R> int launch_symmetrize(R* A, int64_t lda, int n, hipStream_t s);
 // out[0] = 2*sum_i log(L_ii), i < n
-int launch_logdet(const double* L, int64_t ldl, int n, double* out, hipStream_t s);
+template <typename R> int launch_logdet(const R* L, int64_t ldl, int n, double* out, hipStream_t s);
 // out[0] = sum over the lower-triangular tiles of T^2 (T has exact zeros above its diagonal)
-int launch_frob_lower(const double* T, int64_t ldt, int np, double* out, double* partial, hipStream_t s);
+template <typename R>
+int launch_frob_lower(const R* T, int64_t ldt, int np, double* out, double* partial, hipStream_t s);
 // y = L x (L lower, row-major) ; and z = L^T x
-int launch_trmv_lower(const double* L, int64_t ldl, int np, const double* x, double* y, hipStream_t s);
-int launch_trmv_lower_t(const double* L, int64_t ldl, int np, const double* x, double* z, double* partial,
-                        hipStream_t s);
+template <typename R> int launch_trmv_lower(const R* L, int64_t ldl, int np, const R* x, R* y, hipStream_t s);
+template <typename R>
+int launch_trmv_lower_t(const R* L, int64_t ldl, int np, const R* x, R* z, double* partial, hipStream_t s);
 // out[0] = x . y
-int launch_dot(const double* x, const double* y, int n, double* out, hipStream_t s);
+template <typename R> int launch_dot(const R* x, const R* y, int n, double* out, hipStream_t s);
 
 // Latent moments / rate / likelihood pieces in the full-rank original basis:
 //   lam_m = m ; lam_var = Kvec - K~_ii + V_ii ; f = exp(A lam_m + A^2/2 lam_var + lambda0)
 //   scal[0] = r.lam_m  scal[1] = sum r  scal[2] = sum f
 //   wl_i = -1/2 A^2 f_i g_i  with g_i = 1 - J_ii - (pi - delta_ii)(1 - c_ii)/pi
-int launch_moments(const double* Kvec, const double* q, const double* Cos, int64_t ldc, const double* V,
-                   int64_t ldv, const double* m, const double* r, int n, double A, double lambda0,
-                   double* lam_m, double* lam_var, double* f, double* wl, double* scal, hipStream_t s);
+template <typename R>
+int launch_moments(const R* Kvec, const R* q, const R* Cos, int64_t ldc, const R* V, int64_t ldv, const R* m,
+                   const R* r, int n, double A, double lambda0, R* lam_m, R* lam_var, R* f, R* wl, double* scal,
+                   hipStream_t s);
 
 // Adjoint pass over the lower tiles of W (np x np):
 //   w = W_ij - 1/2 b_i b_j ; Aw = w (pi - acos c)/pi ; Bm = w sqrt(1-c^2)/pi
 //   Aw written to Aout symmetric (both triangles), zero on padding;
 //   upart[tj][i] = sum_{j in tile tj} Bm_ij q_j  (+ mirrored contribution -> vpart[ti][j])
 //   sumA_part[tile] = sum of Aw over the tile (off-diagonal tiles counted twice)
-int launch_adjoint(const double* W, const double* Cos, int64_t ld, const double* b, const double* q, int n,
-                   int np, double* Aout, double* upart, double* vpart, double* sumA_part, hipStream_t s);
-// u_i = sum_t upart[t][i] + vpart[t][i];  tvec_i = u_i/q_i - wl_i ; scal_out[0] = sum_i u_i/q_i,
-// scal_out[1] = sum_i wl_i, scal_out[2] = sum of sumA_part
+template <typename R>
+int launch_adjoint(const R* W, const R* Cos, int64_t ld, const R* b, const R* q, int n, int np, R* Aout,
+                   double* upart, double* vpart, double* sumA_part, hipStream_t s);
+// u_i = sum_t upart[t][i] + vpart[t][i];  tvec_i = u_i/q_i - wl_i (uq: fp64 scratch [np]);
+// scal_out[0] = sum_i u_i/q_i, scal_out[1] = sum_i wl_i, scal_out[2] = sum of sumA_part
+template <typename R>
 int launch_adjoint_reduce(const double* upart, const double* vpart, const double* sumA_part, int ntile,
-                          int ntile_tri, const double* q, const double* wl, int n, int np, double* tvec,
+                          int ntile_tri, const R* q, const R* wl, int n, int np, R* tvec, double* uq,
                           double* scal_out, hipStream_t s);
 // Y[n][k] += t[n] * Xm[n][k]
-int launch_rowscale_add(double* Y, int64_t ldy, const double* Xm, int64_t ldm, const double* t, int np,
-                        int dp, hipStream_t s);
+template <typename R>
+int launch_rowscale_add(R* Y, int64_t ldy, const R* Xm, int64_t ldm, const R* t, int np, int dp, hipStream_t s);
 // dst = sum_z src[z] (split-K reduction), count elements each
-int launch_reduce_slices(const double* src, int64_t slice_stride, int nslice, double* dst, int64_t count,
-                         hipStream_t s);
+template <typename RI, typename RO>
+int launch_reduce_slices(const RI* src, int64_t slice_stride, int nslice, RO* dst, int64_t count, hipStream_t s);
 // grad5[p] = sum_kl dC_p[k][l] * M[k][l] for the five metric hyperparameters, dC recomputed from C
-int launch_metric_contract(const Theta& th, const int* pix, int d, int n_rows, int n_cols, const double* C,
-                           int64_t ldc, const double* M, int64_t ldm, double* grad5, hipStream_t s);
+template <typename R>
+int launch_metric_contract(const Theta& th, const int* pix, int d, int n_rows, int n_cols, const R* C, int64_t ldc,
+                           const R* M, int64_t ldm, double* grad5, hipStream_t s);
+template <typename R> int launch_add_diag(R* A, int64_t lda, int n, double v, hipStream_t s);
 
 // ---- helpers of the general (materialising) acosker / localker entry points
 int launch_pad_copy(const double* src, int64_t lds, int rows, int cols, double* dst, int64_t ldd, int prow,
@@ -86,7 +95,6 @@ int launch_dq(const double* Xt, const double* XDt, int64_t ld, int dp, int n, co
 int launch_dk_metric(double* H, int64_t ldh, const double* Cos, int64_t ldc, const double* q1, const double* q2,
                      const double* dq1, const double* dq2, int n1, int n2, hipStream_t s);
 int launch_fill(double* x, int64_t n, double v, hipStream_t s);
-int launch_add_diag(double* A, int64_t lda, int n, double v, hipStream_t s);
 
 // ---- E-step / factorisation / firing-rate helpers
 int launch_estep_prep(const double* f, const double* r, const double* m, int n, int np, double A, double* sv,

@@ -60,9 +60,9 @@ class GPFitEngine:
     def _stream(self):
         return ctypes.c_void_p(torch.cuda.current_stream(self.tdev).cuda_stream)
 
-    def _dev(self, t, name):
-        if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float64):
-            raise TypeError(f"{name} must be a float64 CUDA tensor")
+    def _dev(self, t, name, dtype=torch.float64):
+        if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == dtype):
+            raise TypeError(f"{name} must be a {dtype} CUDA tensor")
         if t.dim() == 2 and t.stride(1) != 1:
             t = t.contiguous()
         if t.dim() == 1 and t.stride(0) != 1:
@@ -97,12 +97,15 @@ class GPFitEngine:
 
         Returns a dict with ``loss`` (= -logmarginal), ``loglik``, ``KL``, ``grad`` (dict in the
         reference's key order, d loss / d theta), diagnostics, and the device vectors
-        ``lam_m, lam_var, f``.  Out-of-box theta returns loss = inf and grad = inf (reference
+        ``lam_m, lam_var, f``.  float32 inputs select the fp32 instance of the library
+        (hyperparameter-grid configuration); float64 is the reference's precision.  Out-of-box theta returns loss = inf and grad = inf (reference
         behaviour); a failed Cholesky raises ``GpfitError``.  ``reuse_V=True`` promises that V is
         the matrix of the previous call on this engine (constant during an M-step) so that its
         factorisation is not repeated."""
         rows, cols = _grid(n_px_side)
-        X, r, m, V = self._dev(X, "X"), self._dev(r, "r"), self._dev(m, "m"), self._dev(V, "V")
+        dtype = X.dtype if isinstance(X, torch.Tensor) and X.dtype == torch.float32 else torch.float64
+        X, r, m, V = (self._dev(X, "X", dtype), self._dev(r, "r", dtype), self._dev(m, "m", dtype),
+                      self._dev(V, "V", dtype))
         N = X.shape[0]
         if X.shape[1] != rows * cols:
             raise ValueError(f"X has {X.shape[1]} pixels but the grid is {rows}x{cols}")
@@ -110,13 +113,14 @@ class GPFitEngine:
         lam_m = lam_var = f = None
         ptrs = [None, None, None]
         if want_vectors:
-            lam_m = torch.empty(N, dtype=torch.float64, device=self.tdev)
+            lam_m = torch.empty(N, dtype=dtype, device=self.tdev)
             lam_var = torch.empty_like(lam_m)
             f = torch.empty_like(lam_m)
             ptrs = [lam_m.data_ptr(), lam_var.data_ptr(), f.data_ptr()]
         lo = _lib.darr(theta_vec(lower)) if lower is not None else None
         up = _lib.darr(theta_vec(upper)) if upper is not None else None
-        rc = self.lib.gpfit_fit_eval(self._ctx, self._stream(), _lib.darr(theta_vec(theta)), lo, up, rows, cols,
+        entry = self.lib.gpfit_fit_eval_f32 if dtype == torch.float32 else self.lib.gpfit_fit_eval
+        rc = entry(self._ctx, self._stream(), _lib.darr(theta_vec(theta)), lo, up, rows, cols,
                                      X.data_ptr(), X.stride(0), N, r.data_ptr(), m.data_ptr(), V.data_ptr(),
                                      V.stride(0), float(logA), float(lambda0), (1 if want_grad else 0) | (2 if reuse_V else 0), out,
                                      ptrs[0], ptrs[1], ptrs[2])

@@ -142,6 +142,16 @@ int gpfit_get_profile(gpfit_ctx* ctx, double* out12);
 /* Host milliseconds the last gpfit_fit_eval spent enqueuing work (before its final sync). */
 double gpfit_last_enqueue_ms(gpfit_ctx* ctx);
 
+/* fp32 instance of the fused unit of work (hyperparameter-grid configuration, BASELINE
+ * configs[4]; the reference itself is fp64-only, utils.py:31-33): X, r, m, V and the optional
+ * output vectors are float32 device buffers, every factorisation / GEMM runs in fp32 on
+ * v_mfma_f32_16x16x4_f32, reductions and the returned scalars are fp64.  Same contract
+ * otherwise.  Accuracy against the fp64 path is stated in tests/test_gpu_fp32.py. */
+int gpfit_fit_eval_f32(gpfit_ctx* ctx, void* stream, const double* theta, const double* lower,
+                       const double* upper, int n_rows, int n_cols, const float* X, int64_t ldx, int64_t N,
+                       const float* r, const float* m, const float* V, int64_t ldv, double logA, double lambda0,
+                       int want_grad, double* out_host, float* lam_m, float* lam_var, float* f);
+
 /* Roofline probes (no reference counterpart): back-to-back v_mfma_f64_16x16x4_f64 issue
  * (flops = blocks*4 waves*iters*16*2048) and a 16-byte-per-lane stream copy. */
 int gpfit_probe_mfma_f64(void* stream, double* scratch, int blocks, int iters);

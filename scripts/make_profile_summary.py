@@ -25,10 +25,10 @@ with open(os.path.join(out_dir, f"{tag}_kernel_stats.csv"), "w") as f:
                     f"{float(r['MinNs'])/1e3:.2f}", f"{float(r['MaxNs'])/1e3:.2f}", r["Percentage"]])
 
 summary = {"source": "rocprofv3 --kernel-trace --stats -- python bench.py --steps 5 --warmup 1 --no-cpu-baseline"}
-gemm = [r for r in stats if "dgemm_mfma_kernel" in r["Name"]]
+gemm = [r for r in stats if "gemm_mfma_kernel" in r["Name"] or "gemm_streamk_kernel" in r["Name"]]
 tot = sum(float(r["TotalDurationNs"]) for r in gemm)
 calls = sum(int(r["Calls"]) for r in gemm)
-summary["dgemm_mfma_kernel"] = {"calls": calls, "total_ms": tot / 1e6, "avg_launch_us": tot / calls / 1e3}
+summary["gemm_mfma_kernel+gemm_streamk_kernel"] = {"calls": calls, "total_ms": tot / 1e6, "avg_launch_us": tot / calls / 1e3}
 allk = sum(float(r["TotalDurationNs"]) for r in stats)
 summary["all_kernels_total_ms"] = allk / 1e6
 
