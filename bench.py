@@ -236,7 +236,7 @@ def main():
             "value": round(fits_per_s, 4), "unit": "fits/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": f"N={N} d={d} single cell fp64, one M-step closure evaluation with 6 gradients "
+            "config": {"workload": f"N={N} d={d} single cell {'fp64' if args.dtype == 'f64' else 'fp32'}, one M-step closure evaluation with 6 gradients "
                                    "(BASELINE configs[2], headline)" if want_grad else f"N={N} d={d} forward only",
                        "N": N, "d": d, "cells_per_gpu": 1, "parallelism": f"independent cells x{world}, X broadcast once over RCCL"},
             "loss": res["loss"],

@@ -7,10 +7,9 @@
  config1  N=4096, d=128 (16x8 pixel grid), single cell, fp64: fits/s
  config3  64 independent cells x N=4096 (d=128), cells sharded cyclically over the ranks,
           X broadcast once over RCCL: cells/s (whole job)
- config4  hyperparameter grid (8x8x8 lattice) x N=8192 (d=256) with gradients, theta points sharded
-          over the ranks; V, m, r are shared by all points, so the V factor is reused
-          (reuse_V).  Run in fp64: the reference is fp64-only and K~ at N=8192 has a condition
-          number ~1e6, where an fp32 Cholesky is unreliable; points/s.
+ config4  hyperparameter grid (8x8x8 lattice) x N=8192 (d=256) with gradients, fp32 instance of the
+          library (gpfit_fit_eval_f32), theta points sharded over the ranks; V, m, r are shared by
+          all points, so the V factor is reused (reuse_V); also run in fp64 for comparison: points/s.
 """
 import argparse, json, os, sys, time
 import torch
@@ -108,7 +107,7 @@ emit(config=f"{cells} independent cells x N=4096 d=128, cyclic shard, X broadcas
 del inputs, eng, V
 torch.cuda.empty_cache()
 
-# ---------------------------------------------------------------- config4: theta grid x N=8192 (fp64)
+# ---------------------------------------------------------------- config4: theta grid x N=8192 (fp32 and fp64)
 N, d = 8192, 256
 grid = syn.grid_for(d)
 X = multi.broadcast_stimuli(torch.from_numpy(syn.stimuli(N, d)) if rank == 0 else None, (N, d), dev).to(dev)
@@ -120,21 +119,30 @@ points = syn.theta_grid(8)
 npts = args.grid_points or 8 * world
 points = points[:npts]
 mine = multi.partition(npts, world, rank)
-first = [True]
+ref_table = None
+for dtype in (torch.float64, torch.float32):
+    Xd, rd, md, Vd = (t.to(dtype) for t in (X, r, m, V))
+    first = [True]
 
+    def eval_point(u):
+        o = eng.fit_eval(points[u], lower, upper, grid, Xd, rd, md, Vd, logA, lam0, want_vectors=False,
+                         reuse_V=not first[0])
+        first[0] = False
+        return [o["loss"]] + [o["grad"][k] for k in syn.THETA_KEYS]
 
-def eval_point(u):
-    o = eng.fit_eval(points[u], lower, upper, grid, X, r, m, V, logA, lam0, want_vectors=False, reuse_V=not first[0])
-    first[0] = False
-    return [o["loss"]] + [o["grad"][k] for k in syn.THETA_KEYS]
-
-
-eval_point(mine[0])
-t0 = sync_time()
-table = multi.run_sharded(npts, eval_point, dev)
-el = max_over_ranks(sync_time() - t0)
-emit(config=f"hyperparameter grid: {npts} of 512 theta points x N=8192 d=256 with gradients, fp64, V factor reused",
-     metric="theta-points/s", value=round(npts / el, 3), n_gpus=world, seconds=round(el, 3),
-     finite=bool(torch.isfinite(table).all()), loss_range=[float(table[:, 0].min()), float(table[:, 0].max())])
+    eval_point(mine[0])
+    t0 = sync_time()
+    table = multi.run_sharded(npts, eval_point, dev)
+    el = max_over_ranks(sync_time() - t0)
+    extra = {}
+    if ref_table is None:
+        ref_table = table
+    else:
+        extra["max_rel_dev_of_loss_vs_fp64"] = float(((table[:, 0] - ref_table[:, 0]).abs() / ref_table[:, 0].abs()).max())
+        extra["max_rel_dev_of_grad_vs_fp64"] = float((table[:, 1:] - ref_table[:, 1:]).abs().max() / ref_table[:, 1:].abs().max())
+    emit(config=f"hyperparameter grid: {npts} of 512 theta points x N=8192 d=256 with gradients, "
+                f"{'fp64' if dtype == torch.float64 else 'fp32'}, V factor reused",
+         metric="theta-points/s", value=round(npts / el, 3), n_gpus=world, seconds=round(el, 3),
+         finite=bool(torch.isfinite(table).all()), **extra)
 if dist is not None:
     dist.destroy_process_group()
