@@ -16,11 +16,12 @@ using namespace gpfit;
 
 static int gemm_full(hipStream_t s, int ak, int bk, int M, int N, int K, double alpha, const double* A, int64_t lda,
                      const double* B, int64_t ldb, double beta, double* C, int64_t ldc, int lower, int at, int bt,
-                     int walk) {
+                     int walk, void* sk_ws) {
   GemmArgs g{};
   g.A = A; g.B = B; g.C = C; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
   g.M = M; g.N = N; g.K = K; g.alpha = alpha; g.beta = beta; g.a_kmajor = ak; g.b_kmajor = bk;
   g.out_lower = lower; g.a_tri = at; g.b_tri = bt; g.batch = 1; g.split_k = 1; g.reverse = walk;
+  g.sk_ws = sk_ws;
   return launch_gemm(g, s);
 }
 
@@ -41,7 +42,7 @@ int gpfit_potrf(gpfit_ctx* c, void* stream, const double* A, int64_t lda, int64_
   const int64_t ld = np;
   GP_HIP(hipMemsetAsync(c->info, 0, 4 * sizeof(int), s));
   GP_TRY(launch_pack_lower(A, lda, (int)n, c->Kbuf, ld, np, s));
-  CholBufs b{c->Kbuf, c->Lbuf, c->Libuf, c->Tmp, ld, c->info};
+  CholBufs b{c->Kbuf, c->Lbuf, c->Libuf, c->Tmp, ld, c->info, 0, c->sk_ws[0]};
   GP_TRY(potrf_rec(b, 0, np, Linv != nullptr, s));
   GP_TRY(launch_logdet(c->Lbuf, ld, (int)n, c->scal + 3, s));
   if (L) GP_TRY(launch_unpack_tri(c->Lbuf, ld, (int)n, L, ldl, s));
@@ -78,12 +79,12 @@ int gpfit_estep(gpfit_ctx* c, void* stream, const double* K, int64_t ldk, int64_
   GP_TRY(launch_estep_prep(f, r, m, n, np, A, sv, rhs, s));
   // M = I + S K S (lower), SK = S K (dense), Kl = K (lower)
   GP_TRY(launch_estep_build(K, ldk, n, np, sv, c->Kbuf, c->Zbuf, c->Wbuf, ld, s));
-  CholBufs b{c->Kbuf, c->Lbuf, c->Libuf, c->Tmp, ld, c->info};
+  CholBufs b{c->Kbuf, c->Lbuf, c->Libuf, c->Tmp, ld, c->info, 0, c->sk_ws[0]};
   GP_TRY(potrf_rec(b, 0, np, true, s));
   // T = L_M^-1 (S K)          lower x dense                         N^3
-  GP_TRY(gemm_full(s, 0, 1, np, np, np, 1.0, c->Libuf, ld, c->Zbuf, ld, 0.0, c->Abuf, ld, 0, 1, 0, 1));
+  GP_TRY(gemm_full(s, 0, 1, np, np, np, 1.0, c->Libuf, ld, c->Zbuf, ld, 0.0, c->Abuf, ld, 0, 1, 0, 1, c->sk_ws[0]));
   // V = K - T^T T             lower tiles only                      N^3
-  GP_TRY(gemm_full(s, 1, 1, np, np, np, -1.0, c->Abuf, ld, c->Abuf, ld, 1.0, c->Wbuf, ld, 1, 0, 0, 0));
+  GP_TRY(gemm_full(s, 1, 1, np, np, np, -1.0, c->Abuf, ld, c->Abuf, ld, 1.0, c->Wbuf, ld, 1, 0, 0, 0, c->sk_ws[0]));
   // m_new = V (A^2 f o m + A (r - f))                                utils.py:1431
   GP_TRY(launch_symv_lower(c->Wbuf, ld, n, rhs, c->tvec, s));
   GP_HIP(hipMemcpyAsync(m_new, c->tvec, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, s));

@@ -57,11 +57,14 @@ struct GemmArgsT {
   int tile;                  // 0 = choose (128 / 64 / 32), else forced block tile
   int reverse;               // tile walk: bit 0 backwards, bit 1 column-major (dense output)
   int workspace;             // stream-K partial-tile workspace to use (0 main stream, 1 aux stream)
+  void* sk_ws;               // caller-owned stream-K workspace (>= SK_WS_BYTES); nullptr: process-wide one
   int tile_limit;            // >0: launch only the first tile_limit tiles of the walk (stream-K head)
 };
 using GemmArgs = GemmArgsT<double>;
 
 // K step staged through LDS: 16 KiB per operand per stage at T = 128 for either type
+constexpr size_t SK_WS_BYTES = (size_t)2 * 512 * TILE * TILE * sizeof(double);  // 2 partial tiles per resident workgroup
+
 template <typename R> constexpr int ktile_of() { return 128 / (int)sizeof(R); }
 
 template <typename R> int launch_gemm(const GemmArgsT<R>& a, hipStream_t s);

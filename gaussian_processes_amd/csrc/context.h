@@ -21,6 +21,7 @@ struct gpfit_ctx {
          *yv = nullptr, *bv = nullptr, *tvec = nullptr /* 2 np */, *mpad = nullptr, *rpad = nullptr,
          *q2 = nullptr, *dq1 = nullptr, *dq2 = nullptr, *hvec = nullptr;
   double *upart = nullptr, *vpart = nullptr, *sumA_part = nullptr, *frob_part = nullptr, *trmv_part = nullptr;
+  void* sk_ws[2] = {nullptr, nullptr};  // stream-K partial-tile workspaces (main / aux stream)
   double* scal = nullptr;       // device scalars [64]
   double* scal_host = nullptr;  // pinned [64]
   int* pix = nullptr;           // device [dfull_cap]
@@ -66,6 +67,7 @@ struct CholBufsT {
   int64_t ld;
   int* info;
   int ws = 0;   // stream-K workspace id (1 for the factorisation running on the aux stream)
+  void* sk_ws = nullptr;  // that workspace (owned by the context)
 };
 using CholBufs = CholBufsT<double>;
 // Recursive blocked Cholesky of the n x n diagonal block at offset r0 (n a multiple of 128),

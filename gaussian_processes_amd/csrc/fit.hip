@@ -16,6 +16,7 @@ namespace gpfit {
 
 // ------------------------------------------------------------------ per-launch profiling
 static thread_local gpfit_ctx* g_prof = nullptr;
+static thread_local void* g_main_sk_ws = nullptr;  // stream-K workspace of the context being evaluated
 
 static hipEvent_t prof_event(gpfit_ctx* c) {
   hipEvent_t e;
@@ -93,7 +94,7 @@ double gemm_flops(const GemmArgsT<R>& g) {
 template <typename R>
 static int gemm(hipStream_t s, int a_kmajor, int b_kmajor, int M, int N, int K, double alpha, const R* A,
                 int64_t lda, const R* B, int64_t ldb, double beta, R* C, int64_t ldc, int out_lower, int a_tri,
-                int b_tri, int reverse = 0, int ws = 0) {
+                int b_tri, int reverse = 0, int ws = 0, void* sk_ws = nullptr) {
   GemmArgsT<R> g{};
   g.A = A; g.B = B; g.C = C;
   g.lda = lda; g.ldb = ldb; g.ldc = ldc;
@@ -101,7 +102,7 @@ static int gemm(hipStream_t s, int a_kmajor, int b_kmajor, int M, int N, int K, 
   g.alpha = alpha; g.beta = beta;
   g.a_kmajor = a_kmajor; g.b_kmajor = b_kmajor;
   g.out_lower = out_lower; g.a_tri = a_tri; g.b_tri = b_tri;
-  g.batch = 1; g.split_k = 1; g.reverse = reverse; g.workspace = ws;
+  g.batch = 1; g.split_k = 1; g.reverse = reverse; g.workspace = ws; g.sk_ws = sk_ws ? sk_ws : g_main_sk_ws;
   // profile kind 0: the 128-tile kernel family (the dominant kernel), 3: the small-tile instances
   ProfScope ps(s, g_prof ? gemm_flops(g) : 0.0, (g_prof && gemm_pick_tile(g) != TILE) ? 3 : 0);
   return launch_gemm(g, s);
@@ -127,14 +128,14 @@ int potrf_rec(const CholBufsT<R>& B, int r0, int n, bool need_inv, hipStream_t s
   const int r1 = r0 + n1;
   GP_TRY(potrf_rec<R>(B, r0, n1, true, s));
   // L21 = A21 * L11^-T       (trsm as a GEMM against the explicit inverse; op(B) = Li11^T is upper)
-  GP_TRY(gemm<R>(s, 0, 0, n2, n1, n1, 1.0, at(B.A, r1, r0), ld, at(B.Li, r0, r0), ld, 0.0, at(B.L, r1, r0), ld, 0, 0, 2, /*walk=*/3, B.ws));
+  GP_TRY(gemm<R>(s, 0, 0, n2, n1, n1, 1.0, at(B.A, r1, r0), ld, at(B.Li, r0, r0), ld, 0.0, at(B.L, r1, r0), ld, 0, 0, 2, /*walk=*/3, B.ws, B.sk_ws));
   // A22 -= L21 L21^T          (syrk, lower tiles only)
-  GP_TRY(gemm<R>(s, 0, 0, n2, n2, n1, -1.0, at(B.L, r1, r0), ld, at(B.L, r1, r0), ld, 1.0, at(B.A, r1, r1), ld, 1, 0, 0, 0, B.ws));
+  GP_TRY(gemm<R>(s, 0, 0, n2, n2, n1, -1.0, at(B.L, r1, r0), ld, at(B.L, r1, r0), ld, 1.0, at(B.A, r1, r1), ld, 1, 0, 0, 0, B.ws, B.sk_ws));
   GP_TRY(potrf_rec<R>(B, r1, n2, need_inv, s));
   if (need_inv) {
     // Li21 = -Li22 * (L21 * Li11)
-    GP_TRY(gemm<R>(s, 0, 1, n2, n1, n1, 1.0, at(B.L, r1, r0), ld, at(B.Li, r0, r0), ld, 0.0, at(B.Tmp, r1, r0), ld, 0, 0, 1, /*walk=*/2, B.ws));
-    GP_TRY(gemm<R>(s, 0, 1, n2, n1, n2, -1.0, at(B.Li, r1, r1), ld, at(B.Tmp, r1, r0), ld, 0.0, at(B.Li, r1, r0), ld, 0, 1, 0, /*walk=*/1, B.ws));
+    GP_TRY(gemm<R>(s, 0, 1, n2, n1, n1, 1.0, at(B.L, r1, r0), ld, at(B.Li, r0, r0), ld, 0.0, at(B.Tmp, r1, r0), ld, 0, 0, 1, /*walk=*/2, B.ws, B.sk_ws));
+    GP_TRY(gemm<R>(s, 0, 1, n2, n1, n2, -1.0, at(B.Li, r1, r1), ld, at(B.Tmp, r1, r0), ld, 0.0, at(B.Li, r1, r0), ld, 0, 1, 0, /*walk=*/1, B.ws, B.sk_ws));
   }
   return 0;
 }
@@ -240,6 +241,7 @@ static int fit_eval_impl(gpfit_ctx* c, void* stream, const double* theta, const 
   c->cur_n = n; c->cur_np = np; c->cur_d = d; c->cur_dp = dp;
 
   const auto t_host0 = std::chrono::steady_clock::now();
+  g_main_sk_ws = c->sk_ws[0];
   prof_begin(c);
   struct ProfGuard { gpfit_ctx* c; ~ProfGuard() { prof_end(c); } } prof_guard{c};
   GP_HIP(hipMemsetAsync(c->info, 0, 4 * sizeof(int), s));
@@ -258,7 +260,7 @@ static int fit_eval_impl(gpfit_ctx* c, void* stream, const double* theta, const 
   if (!reuse_V) {
     c->lv_valid = false;
     GP_TRY(launch_pack_lower(V, ldv, n, RP(c->Vbuf), ld, np, sa));
-    CholBufsT<R> bv{RP(c->Vbuf), RP(c->LVbuf), RP(c->LiVbuf), RP(c->TmpV), ld, c->info + 1, 1};
+    CholBufsT<R> bv{RP(c->Vbuf), RP(c->LVbuf), RP(c->LiVbuf), RP(c->TmpV), ld, c->info + 1, 1, c->sk_ws[1]};
     GP_TRY(potrf_rec<R>(bv, 0, np, false, sa));
     GP_TRY(launch_logdet(RP(c->LVbuf), ld, n, c->scal + 40, sa));
   }
@@ -280,7 +282,7 @@ static int fit_eval_impl(gpfit_ctx* c, void* stream, const double* theta, const 
   GP_TRY(launch_moments(RP(c->Kvec), RP(c->q), RP(c->Cos), ld, V, ldv, m, r, n, A, lambda0, RP(c->lam_m), RP(c->lam_var), RP(c->fvec),
                         RP(c->wl), c->scal, s));
   {
-    CholBufsT<R> bk{RP(c->Kbuf), RP(c->Lbuf), RP(c->Libuf), RP(c->Tmp), ld, c->info + 0};
+    CholBufsT<R> bk{RP(c->Kbuf), RP(c->Lbuf), RP(c->Libuf), RP(c->Tmp), ld, c->info + 0, 0, c->sk_ws[0]};
     GP_TRY(potrf_rec<R>(bk, 0, np, true, s));
   }
   GP_TRY(launch_logdet(RP(c->Lbuf), ld, n, c->scal + 3, s));
@@ -426,6 +428,11 @@ int gpfit_ctx_create(int device, int64_t n_max, int64_t d_max, int64_t d_full_ma
   A(&c->upart, t64 * np); A(&c->vpart, t64 * np); A(&c->sumA_part, t64 * (t64 + 1) / 2);
   A(&c->frob_part, (np / TILE) * (np / TILE + 1) / 2); A(&c->trmv_part, (np / 512 + 1) * np);
   A(&c->scal, 64);
+  for (int i = 0; i < 2 && !rc; ++i) {
+    double* w = nullptr;
+    rc = dev_alloc(c, &w, SK_WS_BYTES / sizeof(double));
+    c->sk_ws[i] = w;
+  }
   if (!rc) rc = dev_alloc(c, &c->pix, (size_t)c->dfull_cap);
   if (!rc) rc = dev_alloc(c, &c->info, 4);
   if (rc) {

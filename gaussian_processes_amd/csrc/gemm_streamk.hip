@@ -110,11 +110,14 @@ template <typename R>
 __global__ __launch_bounds__(256) void streamk_fixup_kernel(SkParams<R> p, const int* __restrict__ fix_tile,
                                                             const int* __restrict__ fix_ptr,
                                                             const int* __restrict__ fix_slot) {
+  // grid = (split tiles, 8): each workgroup sums a 16-row band, so that a launch with few split
+  // tiles but many partials per tile (short tails) still spreads over the chip
   const SkTile tl = p.tiles[fix_tile[blockIdx.x]];
   const int s0 = fix_ptr[blockIdx.x], s1 = fix_ptr[blockIdx.x + 1];
   const R alpha = (R)p.alpha, beta = (R)p.beta;
-  for (int e = threadIdx.x; e < TILE * TILE; e += blockDim.x) {
-    const int r = e >> 7, c = e & 127;
+  const int band = TILE / (int)gridDim.y;
+  for (int e = threadIdx.x; e < band * TILE; e += blockDim.x) {
+    const int r = blockIdx.y * band + (e >> 7), c = e & 127;
     R sum = 0;
     for (int s = s0; s < s1; ++s) sum += p.partial[(int64_t)fix_slot[s] * (TILE * TILE) + r * TILE + c];
     R* cp = p.C + (int64_t)(tl.row0 + r) * p.ldc + tl.col0 + c;
@@ -155,7 +158,8 @@ static int build_plan(const GemmArgsT<R>& a, int first, SkPlan& plan) {
   plan.ntiles = ntiles;
   if (prefix >= (1LL << 31)) return 1;
   plan.total = (int)prefix;
-  plan.blocks = (int)std::min<long long>(SK_SLOTS, prefix);
+  // at most 16 shares per tile: finer cuts only add partial-tile traffic and fix-up work
+  plan.blocks = (int)std::min<long long>(std::min<long long>(SK_SLOTS, (long long)ntiles * 16), prefix);
   plan.per_block = (int)((prefix + plan.blocks - 1) / plan.blocks);
   // replay the kernel's walk to list, per split tile, the slots in accumulation (block) order
   std::vector<std::vector<int>> slots(ntiles);
@@ -233,7 +237,7 @@ int launch_gemm_streamk(const GemmArgsT<R>& a, hipStream_t s) {
       itp = g_plans.emplace(key, np).first;
     }
     plan = itp->second;
-    if (!g_workspace[ws]) GP_HIP(hipMalloc(&g_workspace[ws], (size_t)2 * SK_SLOTS * TILE * TILE * sizeof(double)));
+    if (!a.sk_ws && !g_workspace[ws]) GP_HIP(hipMalloc(&g_workspace[ws], SK_WS_BYTES));
   }
   if (first > 0) {  // the full rounds, data-parallel
     GemmArgsT<R> head = a;
@@ -245,7 +249,7 @@ int launch_gemm_streamk(const GemmArgsT<R>& a, hipStream_t s) {
   SkParams<R> p{};
   p.A = a.A; p.B = a.B; p.C = a.C; p.lda = a.lda; p.ldb = a.ldb; p.ldc = a.ldc; p.M = a.M; p.N = a.N;
   p.alpha = a.alpha; p.beta = a.beta; p.tiles = plan.tiles; p.ntiles = plan.ntiles; p.total = plan.total;
-  p.per_block = plan.per_block; p.partial = (R*)g_workspace[ws];
+  p.per_block = plan.per_block; p.partial = (R*)(a.sk_ws ? a.sk_ws : g_workspace[ws]);
   dim3 grid(plan.blocks), block(GEMM_THREADS);
   const int sel = (a.a_kmajor ? 2 : 0) | (a.b_kmajor ? 1 : 0);
   switch (sel) {
@@ -255,7 +259,7 @@ int launch_gemm_streamk(const GemmArgsT<R>& a, hipStream_t s) {
     case 3: hipLaunchKernelGGL((gemm_streamk_kernel<R, true, true>), grid, block, 0, s, p); break;
   }
   if (plan.nfix)
-    hipLaunchKernelGGL(streamk_fixup_kernel<R>, dim3(plan.nfix), dim3(256), 0, s, p, plan.fix_tile, plan.fix_ptr,
+    hipLaunchKernelGGL(streamk_fixup_kernel<R>, dim3(plan.nfix, 8), dim3(256), 0, s, p, plan.fix_tile, plan.fix_ptr,
                        plan.fix_slot);
   GP_HIP(hipGetLastError());
   return 0;
