@@ -36,7 +36,7 @@ struct gpfit_ctx {
   struct ProfRec { hipEvent_t a, b; double flops; int kind; };  // kind 0 gemm T=128, 1 leaf, 2 gram, 3 gemm T<128
   std::vector<ProfRec> prof;
   std::vector<hipEvent_t> ev_pool;
-  double prof_out[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  double prof_out[16] = {0};
   double last_enqueue_ms = 0.0;  // host time spent enqueuing the last fit_eval
 
   // cached state of the last upload / evaluation (used by estep / predict entry points)

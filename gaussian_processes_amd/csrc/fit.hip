@@ -41,9 +41,11 @@ void prof_end(gpfit_ctx* c) {
   g_prof = nullptr;
   (void)hipDeviceSynchronize();
   double ms[4] = {0, 0, 0, 0}, fl[4] = {0, 0, 0, 0}, cnt[4] = {0, 0, 0, 0};
+  double big_ms = 0, big_fl = 0;
   for (auto& r : c->prof) {
     float t = 0.f;
     (void)hipEventElapsedTime(&t, r.a, r.b);
+    if (r.kind == 0 && r.flops > big_fl) { big_fl = r.flops; big_ms = t; }
     ms[r.kind] += t;
     fl[r.kind] += r.flops;
     cnt[r.kind] += 1;
@@ -55,6 +57,7 @@ void prof_end(gpfit_ctx* c) {
   c->prof_out[3] = ms[1]; c->prof_out[4] = cnt[1];
   c->prof_out[5] = ms[2]; c->prof_out[6] = fl[2]; c->prof_out[7] = cnt[2];
   c->prof_out[8] = ms[3]; c->prof_out[9] = fl[3]; c->prof_out[10] = cnt[3];
+  c->prof_out[11] = big_ms; c->prof_out[12] = big_fl;
 }
 
 ProfScope::ProfScope(hipStream_t s_, double flops_, int kind_) : s(s_), flops(flops_), kind(kind_) {
@@ -478,9 +481,9 @@ int gpfit_set_profile(gpfit_ctx* c, int on) {
 
 double gpfit_last_enqueue_ms(gpfit_ctx* c) { return c ? c->last_enqueue_ms : -1.0; }
 
-int gpfit_get_profile(gpfit_ctx* c, double* out12) {
-  if (!c || !out12) return -3;
-  for (int i = 0; i < 12; ++i) out12[i] = c->prof_out[i];
+int gpfit_get_profile(gpfit_ctx* c, double* out16) {
+  if (!c || !out16) return -3;
+  for (int i = 0; i < 16; ++i) out16[i] = c->prof_out[i];
   return 0;
 }
 

@@ -3,6 +3,7 @@
 #include "gemm_core.h"
 
 #include <algorithm>
+#include <cstdlib>
 
 namespace gpfit {
 
@@ -84,7 +85,8 @@ int gemm_pick_tile(const GemmArgsT<R>& a) {
     return (a.out_lower ? (long)lower_tile_count((int)nb, TILE / T) : tm * tn) * (a.batch > 0 ? a.batch : 1) *
            (a.split_k > 1 ? a.split_k : 1);
   };
-  if (ntiles(128) >= 384) return 128;
+  static const long t128_min = getenv("GPFIT_T128_MIN") ? atol(getenv("GPFIT_T128_MIN")) : 384;
+  if (ntiles(128) >= t128_min) return 128;
   if (ntiles(64) >= 256) return 64;
   return (a.M <= 1024 && a.N <= 1024) ? 32 : 64;
 }

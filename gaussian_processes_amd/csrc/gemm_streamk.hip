@@ -215,10 +215,12 @@ int launch_gemm_streamk(const GemmArgsT<R>& a, hipStream_t s) {
   if ((a.M % TILE) || (a.N % TILE) || a.split_k > 1 || a.batch > 1 || (a.tile && a.tile != TILE)) return 1;
   const long tm = a.M / TILE, tn = a.N / TILE;
   const int ntiles = (int)(a.out_lower ? tm * (tm + 1) / 2 : tm * tn);
-  if (ntiles < 384 || (long)a.K < 1024) return 1;  // small launches: latency-, not balance-bound
+  static const int sk_min = getenv("GPFIT_SK_MIN_TILES") ? atoi(getenv("GPFIT_SK_MIN_TILES")) : 384;
+  static const int sk_all = getenv("GPFIT_SK_ALL") ? 1 : 0;  // experiment: stream-K for every eligible launch
+  if (ntiles < sk_min || (long)a.K < 1024) return 1;  // small launches: latency-, not balance-bound
   int first = 0;
   const bool both_tri = (a.a_tri != 0 && a.b_tri != 0) || (a.out_lower && a.a_tri == 2);
-  if (!both_tri) {
+  if (!both_tri && !(sk_all && ntiles < SK_SLOTS)) {
     if (a.a_tri || a.b_tri) return 1;       // one-sided triangles: the heavy-first walk already balances
     const int tail = ntiles % SK_SLOTS;
     if (tail == 0 || tail >= 384 || ntiles < SK_SLOTS) return 1;

@@ -73,11 +73,12 @@ class GPFitEngine:
         _lib.check(self.lib.gpfit_set_profile(self._ctx, 1 if on else 0), "gpfit_set_profile")
 
     def get_profile(self):
-        out = (ctypes.c_double * 12)()
+        out = (ctypes.c_double * 16)()
         _lib.check(self.lib.gpfit_get_profile(self._ctx, out), "gpfit_get_profile")
         return {"gemm_ms": out[0], "gemm_flops": out[1], "gemm_launches": int(out[2]), "leaf_ms": out[3],
                 "leaf_launches": int(out[4]), "gram_ms": out[5], "gram_flops": out[6],
-                "small_gemm_ms": out[8], "small_gemm_flops": out[9], "small_gemm_launches": int(out[10])}
+                "small_gemm_ms": out[8], "small_gemm_flops": out[9], "small_gemm_launches": int(out[10]),
+                "largest_gemm_ms": out[11], "largest_gemm_flops": out[12]}
 
     def last_enqueue_ms(self) -> float:
         return float(self.lib.gpfit_last_enqueue_ms(self._ctx))

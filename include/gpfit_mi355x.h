@@ -133,12 +133,13 @@ int gpfit_fparam_eval(gpfit_ctx* ctx, void* stream, const double* lam_m, const d
 
 /* Per-launch HIP-event timing of the dominant kernels during gpfit_fit_eval (bench.py's
  * roofline leg; adds two event records per launch, so leave it off when timing throughput).
- * out12: 0 sum of the 128-tile dgemm launch durations [ms] (the dominant kernel family, stream-K
+ * out16: 0 sum of the 128-tile GEMM launch durations [ms] (the dominant kernel family, stream-K
  *        variant included), 1 flops those launches executed, 2 #launches, 3 sum of Cholesky-leaf
  *        durations [ms], 4 #leaves, 5 Gram kernel [ms], 6 its flops, 7 #, 8-10 the same three
- *        figures for the 64/32-tile dgemm instances, 11 unused. */
+ *        figures for the 64/32-tile instances, 11-12 duration [ms] and flops of the single largest
+ *        GEMM launch (Q L^-1 at the headline), 13-15 unused. */
 int gpfit_set_profile(gpfit_ctx* ctx, int on);
-int gpfit_get_profile(gpfit_ctx* ctx, double* out12);
+int gpfit_get_profile(gpfit_ctx* ctx, double* out16);
 /* Host milliseconds the last gpfit_fit_eval spent enqueuing work (before its final sync). */
 double gpfit_last_enqueue_ms(gpfit_ctx* ctx);
 
