@@ -4,16 +4,18 @@
 //
 // Block = 256 threads = 4 waves (2 x 2), block tile T x T (T = 128 for large problems; 64 / 32
 // so that small panels of the recursive Cholesky still spread over many CUs), K step of
-// 16 (fp64) / 32 (fp32) staged through LDS, wave tile T/2 x T/2 of 16 x 16 x 4 MFMA tiles
-// (4 x 4 accumulators at T = 128).
-// Operands are staged global -> registers -> LDS with a one-tile register prefetch and two
-// LDS buffers (one barrier per K step).  Both operands sit in LDS "k-major" ([KT][T], the M/N
-// index contiguous) so that an MFMA fragment read is one ds_read per lane over 16 consecutive
-// elements per k row; the column index is XOR-swizzled with the k row so that (a) the two k rows
-// a 32-lane half reads fall in different bank halves and (b) the stores that transpose a
-// k-contiguous source on the way in spread over the banks.
+// 16 (fp64) / 32 (fp32) = 128 bytes per operand row, wave tile T/2 x T/2 of 16 x 16 x 4 MFMA
+// tiles (4 x 4 accumulators at T = 128), two LDS buffers, one barrier per K step.
+//
+// Full-tile instances stage operands global -> LDS by DMA (buffer_load_dwordx4 ... lds), with
+// the bank-conflict permutation applied on the source address; MFMA fragments are double-buffered
+// in registers so every LDS wait sits behind 16 MFMAs (gemm_mainloop below: 189 VGPRs at T = 128,
+// 2 blocks / CU; plain 8192^3 fp64 at 72-73 TFLOP/s = 0.92-0.94 of the matrix peak).  Ragged
+// (EDGE) instances keep a register-staged loop with swizzled k-major images (zero fill per row).
 #pragma once
 #include "common.h"
+
+#include <cstdint>
 
 namespace gpfit {
 
@@ -58,25 +60,40 @@ template <typename R> __device__ __forceinline__ typename Real<R>::acc_t acc_zer
 // Global -> registers: T/32 x 16-byte chunks per thread for one T x KT operand tile.
 //   KMAJOR  : source element (x,k) at P[k*ld + x]  (x contiguous)  -> chunk = (k, EPC x's)
 //   !KMAJOR : source element (x,k) at P[x*ld + k]  (k contiguous)  -> chunk = (x, EPC k's)
-template <typename R, bool KMAJOR, bool EDGE, int T>
-__device__ __forceinline__ void tile_gload(typename Real<R>::vec_t (&r)[T / 32], const R* __restrict__ P, int64_t ld,
-                                           int x0, int k0, int X, int tid) {
-  using V = typename Real<R>::vec_t;
-  constexpr int EPC = Real<R>::EPC;
+// The address is split into a wave-uniform base (tile origin, advanced by a scalar add per K
+// step) and per-thread byte offsets computed once before the loop, so that a K step costs one
+// global_load (SGPR base + VGPR offset) per chunk and no address arithmetic.
+template <typename R, bool KMAJOR, bool EDGE, int T> struct TileSrc {
+  const char* base;     // uniform: &P[(k0, x0)]
+  int64_t step;         // bytes per K step
+  uint32_t off[T / 32];  // per-thread byte offsets of the chunks within the tile
+  uint32_t valid;        // EDGE: bit i = chunk i inside the matrix
+
+  __device__ __forceinline__ void init(const R* __restrict__ P, int64_t ld, int x0, int k0, int X, int tid) {
+    constexpr int EPC = Real<R>::EPC, KT = Real<R>::KT;
+    base = reinterpret_cast<const char*>(KMAJOR ? P + (int64_t)k0 * ld + x0 : P + (int64_t)x0 * ld + k0);
+    step = (KMAJOR ? (int64_t)KT * ld : (int64_t)KT) * (int64_t)sizeof(R);
+    valid = 0;
 #pragma unroll
-  for (int i = 0; i < T / 32; ++i) {
-    const int c = tid + GEMM_THREADS * i;
-    if (KMAJOR) {
-      const int k = c / (T / EPC), x = x0 + EPC * (c % (T / EPC));
-      if (!EDGE || x < X) r[i] = *reinterpret_cast<const V*>(P + (int64_t)(k0 + k) * ld + x);
-      else r[i] = V{};
-    } else {
-      const int x = x0 + (c >> 3), k = k0 + EPC * (c & 7);
-      if (!EDGE || x < X) r[i] = *reinterpret_cast<const V*>(P + (int64_t)x * ld + k);
+    for (int i = 0; i < T / 32; ++i) {
+      const int c = tid + GEMM_THREADS * i;
+      int x, k;
+      if (KMAJOR) { k = c / (T / EPC); x = EPC * (c % (T / EPC)); }
+      else { x = c >> 3; k = EPC * (c & 7); }
+      off[i] = (uint32_t)((KMAJOR ? (int64_t)k * ld + x : (int64_t)x * ld + k) * (int64_t)sizeof(R));
+      if (!EDGE || x0 + x < X) valid |= 1u << i;
+    }
+  }
+  __device__ __forceinline__ void load(typename Real<R>::vec_t (&r)[T / 32]) const {
+    using V = typename Real<R>::vec_t;
+#pragma unroll
+    for (int i = 0; i < T / 32; ++i) {
+      if (!EDGE || ((valid >> i) & 1u)) r[i] = *reinterpret_cast<const V*>(base + off[i]);
       else r[i] = V{};
     }
   }
-}
+  __device__ __forceinline__ void advance() { base += step; }
+};
 
 // Registers -> LDS (swizzled k-major image [KT][T]).
 template <typename R, bool KMAJOR, int T>
@@ -100,10 +117,14 @@ __device__ __forceinline__ void tile_sstore(const typename Real<R>::vec_t (&r)[T
 // acc[mi][ni] += op(A)[row0.., k] * op(B)[k, col0..] over k in [kbeg, kend) (multiples of KT).
 // Block tile T x T (T = 128, 64 or 32), 4 waves as 2 x 2, wave tile T/2 x T/2.
 // smem: 4 * KT * T elements: [buf][A|B][KT][T].
-template <typename R, bool A_KMAJOR, bool B_KMAJOR, bool EDGE, int T>
-__device__ __forceinline__ void gemm_mainloop(const R* __restrict__ A, int64_t lda, const R* __restrict__ B,
-                                              int64_t ldb, int M, int N, int row0, int col0, int kbeg, int kend,
-                                              R* smem, typename Real<R>::acc_t (&acc)[T / 32][T / 32]) {
+// ---------------------------------------------------------------------------------------------
+// Register-staged main loop (EDGE instances only: ragged M / N need the per-row zero fill).
+// acc[mi][ni] += op(A)[row0.., k] * op(B)[k, col0..] over k in [kbeg, kend) (multiples of KT).
+// smem: 4 * KT * T elements: [buf][A|B][KT][T] swizzled k-major images.
+template <typename R, bool A_KMAJOR, bool B_KMAJOR, int T>
+__device__ __forceinline__ void gemm_mainloop_regstage(const R* __restrict__ A, int64_t lda, const R* __restrict__ B,
+                                                       int64_t ldb, int M, int N, int row0, int col0, int kbeg,
+                                                       int kend, R* smem, typename Real<R>::acc_t (&acc)[T / 32][T / 32]) {
   using V = typename Real<R>::vec_t;
   constexpr int MI = T / 32, WT = T / 2, KT = Real<R>::KT, LT = KT * T;
   const int tid = threadIdx.x;
@@ -113,21 +134,29 @@ __device__ __forceinline__ void gemm_mainloop(const R* __restrict__ A, int64_t l
   V ra[MI], rb[MI];
 
   if (kbeg >= kend) return;
-  tile_gload<R, A_KMAJOR, EDGE, T>(ra, A, lda, row0, kbeg, M, tid);
-  tile_gload<R, B_KMAJOR, EDGE, T>(rb, B, ldb, col0, kbeg, N, tid);
+  TileSrc<R, A_KMAJOR, true, T> sa;
+  TileSrc<R, B_KMAJOR, true, T> sb;
+  sa.init(A, lda, row0, kbeg, M, tid);
+  sb.init(B, ldb, col0, kbeg, N, tid);
+  sa.load(ra);
+  sb.load(rb);
+  __syncthreads();
   tile_sstore<R, A_KMAJOR, T>(ra, smem, tid);
   tile_sstore<R, B_KMAJOR, T>(rb, smem + LT, tid);
   __syncthreads();
-
+  if (kbeg + KT < kend) {
+    sa.advance();
+    sb.advance();
+    sa.load(ra);
+    sb.load(rb);
+  }
   int buf = 0;
   for (int k0 = kbeg; k0 < kend; k0 += KT) {
     const bool more = (k0 + KT) < kend;
-    if (more) {
-      tile_gload<R, A_KMAJOR, EDGE, T>(ra, A, lda, row0, k0 + KT, M, tid);
-      tile_gload<R, B_KMAJOR, EDGE, T>(rb, B, ldb, col0, k0 + KT, N, tid);
-    }
+    const bool more2 = (k0 + 2 * KT) < kend;
     const R* As = smem + buf * 2 * LT;
     const R* Bs = As + LT;
+    R* Sn = smem + (buf ^ 1) * 2 * LT;
 #pragma unroll
     for (int kk = 0; kk < KT / 4; ++kk) {
       const int krow = kk * 4 + fk;
@@ -142,14 +171,159 @@ __device__ __forceinline__ void gemm_mainloop(const R* __restrict__ A, int64_t l
       for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
         for (int ni = 0; ni < MI; ++ni) acc[mi][ni] = Real<R>::mfma(a[mi], b[ni], acc[mi][ni]);
-    }
-    if (more) {
-      R* Sn = smem + (buf ^ 1) * 2 * LT;
-      tile_sstore<R, A_KMAJOR, T>(ra, Sn, tid);
-      tile_sstore<R, B_KMAJOR, T>(rb, Sn + LT, tid);
+      if (kk == KT / 8 && more) {
+        tile_sstore<R, A_KMAJOR, T>(ra, Sn, tid);
+        tile_sstore<R, B_KMAJOR, T>(rb, Sn + LT, tid);
+        if (more2) {
+          sa.advance();
+          sb.advance();
+          sa.load(ra);
+          sb.load(rb);
+        }
+      }
     }
     __syncthreads();
     buf ^= 1;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// LDS-DMA main loop (all full-tile instances).  Operand tiles go global -> LDS directly
+// (buffer_load_dwordx4 ... lds: 64 lanes x 16 B = 1 KiB of LDS per wave-instruction, written
+// lane-linearly), so the staging costs no VGPRs and no ds_write pass.  The LDS image of an operand
+// depends on how its source is laid out (a DMA cannot transpose):
+//   k-major source   ([k][x], x contiguous): image [KT][T], column index XOR 16*(k & SWK)
+//       (the rows of one MFMA fragment read, 1 KiB apart, land in different bank groups);
+//   k-contiguous source ([x][k]):            image [T][KT] (one 128-byte row per x), the eight
+//       16-byte chunks of a row XOR-permuted by (x >> 1) & 7 (16 rows of a fragment read hit 16
+//       different bank groups).
+// Both permutations are applied on the SOURCE address of the DMA (per-lane) and again on the
+// fragment read; the LDS write itself stays linear.
+template <typename R, int T> struct LdsImage {
+  static constexpr int EPC = Real<R>::EPC, KT = Real<R>::KT;
+  static constexpr int SWK = (EPC == 2 ? 1 : 3) & (T / 16 - 1);
+  // element offset of (x, k) in the image
+  template <bool KMAJOR> static __device__ __forceinline__ int at(int x, int k) {
+    if (KMAJOR) return k * T + (x ^ (16 * (k & SWK)));
+    return x * KT + ((((k / EPC) ^ ((x >> 1) & 7))) * EPC) + (k % EPC);
+  }
+};
+
+template <typename R, bool KMAJOR, int T> struct TileDma {
+  static constexpr int MI = T / 32, EPC = Real<R>::EPC, KT = Real<R>::KT;
+  const char* base;   // wave-uniform: &P[(k0, x0)]
+  int64_t step;       // bytes per K step
+  uint32_t voff[MI];  // per-lane source byte offsets of this wave's MI instructions
+  int q0;             // first instruction index of this wave (LDS destination = q * 1 KiB)
+
+  __device__ __forceinline__ void init(const R* __restrict__ P, int64_t ld, int x0, int k0, int wave, int lane) {
+    base = reinterpret_cast<const char*>(KMAJOR ? P + (int64_t)k0 * ld + x0 : P + (int64_t)x0 * ld + k0);
+    step = (KMAJOR ? (int64_t)KT * ld : (int64_t)KT) * (int64_t)sizeof(R);
+    q0 = wave * MI;
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      const int pch = (q0 + i) * 64 + lane;  // 16-byte chunk index inside the image
+      int64_t e;
+      if (KMAJOR) {
+        constexpr int CPR = T / EPC;
+        const int k = pch / CPR, xs = (pch % CPR) * EPC;
+        e = (int64_t)k * ld + (xs ^ (16 * (k & LdsImage<R, T>::SWK)));
+      } else {
+        const int x = pch >> 3, j = (pch & 7) ^ ((x >> 1) & 7);
+        e = (int64_t)x * ld + j * EPC;
+      }
+      voff[i] = (uint32_t)(e * (int64_t)sizeof(R));
+    }
+  }
+  // image: LDS byte address of the operand image this tile goes to (wave-uniform)
+  __device__ __forceinline__ void issue(uint32_t image) const {
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(base), 0, -1, 0x00020000);
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(
+          rs, (__attribute__((address_space(3))) void*)(uintptr_t)(image + (uint32_t)(q0 + i) * 1024u), 16, voff[i], 0, 0, 0);
+  }
+  __device__ __forceinline__ void advance() { base += step; }
+};
+
+// ABL: ablation bits for scripts/dev_gemm_abl.hip only (1 no barrier, 2 no DMA in the loop);
+// product code uses 0.
+template <typename R, bool A_KMAJOR, bool B_KMAJOR, bool EDGE, int T, int ABL = 0>
+__device__ __forceinline__ void gemm_mainloop(const R* __restrict__ A, int64_t lda, const R* __restrict__ B,
+                                              int64_t ldb, int M, int N, int row0, int col0, int kbeg, int kend,
+                                              R* smem, typename Real<R>::acc_t (&acc)[T / 32][T / 32]) {
+  if constexpr (EDGE) {
+    gemm_mainloop_regstage<R, A_KMAJOR, B_KMAJOR, T>(A, lda, B, ldb, M, N, row0, col0, kbeg, kend, smem, acc);
+    return;
+  } else {
+    constexpr int MI = T / 32, WT = T / 2, KT = Real<R>::KT, LT = KT * T, NKK = KT / 4;
+    using Img = LdsImage<R, T>;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int fr = lane & 15, fk = lane >> 4;
+    row0 = __builtin_amdgcn_readfirstlane(row0);
+    col0 = __builtin_amdgcn_readfirstlane(col0);
+    kbeg = __builtin_amdgcn_readfirstlane(kbeg);
+    kend = __builtin_amdgcn_readfirstlane(kend);
+    if (kbeg >= kend) return;
+
+    TileDma<R, A_KMAJOR, T> da;
+    TileDma<R, B_KMAJOR, T> db;
+    da.init(A, lda, row0, kbeg, wave, lane);
+    db.init(B, ldb, col0, kbeg, wave, lane);
+    const uint32_t lds0 = (uint32_t)(uintptr_t)smem;  // low 32 bits of a generic LDS pointer = LDS address
+    constexpr uint32_t LTB = LT * sizeof(R);
+
+    __syncthreads();  // a previous tile's readers (stream-K) are done with both buffers
+    da.issue(lds0);
+    db.issue(lds0 + LTB);
+    __syncthreads();  // vmcnt(0): the DMA of every wave has landed
+
+    // MFMA fragments are double-buffered in registers across the kk sub-steps: the ds_reads of
+    // sub-step kk+1 are issued BEFORE the 16 MFMAs of sub-step kk.  The single barrier of a K
+    // step sits before the MFMAs of the last sub-step and is followed by the first fragment
+    // reads of the next buffer, so both waits are covered by those MFMAs; the DMA of the next
+    // tile is issued at the top of the step (its buffer's readers passed the previous barrier).
+    R fa[2][MI], fb[2][MI];
+    auto frag = [&](const R* S, int kk, R (&a)[MI], R (&b)[MI]) {
+      const int k = kk * 4 + fk;
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+        a[i] = S[Img::template at<A_KMAJOR>(wm * WT + i * 16 + fr, k)];
+        b[i] = S[LT + Img::template at<B_KMAJOR>(wn * WT + i * 16 + fr, k)];
+      }
+    };
+    frag(smem, 0, fa[0], fb[0]);
+
+    int buf = 0;
+    for (int k0 = kbeg; k0 < kend; k0 += KT) {
+      const bool more = (k0 + KT) < kend;
+      const R* Sc = smem + buf * 2 * LT;
+      const R* Sn = smem + (buf ^ 1) * 2 * LT;
+      if (more && !(ABL & 2)) {
+        da.advance();
+        db.advance();
+        const uint32_t img = lds0 + (uint32_t)(buf ^ 1) * 2u * LTB;
+        da.issue(img);
+        db.issue(img + LTB);
+      }
+#pragma unroll
+      for (int kk = 0; kk < NKK; ++kk) {
+        const int cur = kk & 1, nxt = cur ^ 1;
+        if (kk + 1 < NKK) {
+          frag(Sc, kk + 1, fa[nxt], fb[nxt]);
+        } else if (more) {
+          if (!(ABL & 1)) __syncthreads();
+          frag(Sn, 0, fa[nxt], fb[nxt]);
+        }
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < MI; ++ni) acc[mi][ni] = Real<R>::mfma(fa[cur][mi], fb[cur][ni], acc[mi][ni]);
+      }
+      buf ^= 1;
+    }
   }
 }
 
