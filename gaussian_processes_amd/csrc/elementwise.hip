@@ -648,6 +648,28 @@ int launch_add_diag(R* A, int64_t lda, int n, double v, hipStream_t s) {
   return 0;
 }
 
+// dst[r][c] = a * dst[r][c] + b * src[r][c] over a rows x cols block (cols even, 16-byte rows)
+template <typename R>
+__global__ void axpby_block_kernel(R* __restrict__ dst, int64_t ldd, const R* __restrict__ src, int64_t lds, int rows,
+                                   int cols, R a, R b) {
+  const int c = (blockIdx.x * blockDim.x + threadIdx.x) * 2;
+  const int r = blockIdx.y;
+  if (c >= cols || r >= rows) return;
+  R* d = dst + (int64_t)r * ldd + c;
+  const R* q = src + (int64_t)r * lds + c;
+  d[0] = a * d[0] + b * q[0];
+  d[1] = a * d[1] + b * q[1];
+}
+
+template <typename R>
+int launch_axpby_block(R* dst, int64_t ldd, const R* src, int64_t lds, int rows, int cols, double a, double b,
+                       hipStream_t s) {
+  hipLaunchKernelGGL(axpby_block_kernel<R>, dim3((cols / 2 + 255) / 256, rows), dim3(256), 0, s, dst, ldd, src, lds,
+                     rows, cols, (R)a, (R)b);
+  GP_HIP(hipGetLastError());
+  return 0;
+}
+
 __global__ void fill_kernel(double* __restrict__ x, int64_t n, double v) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) x[i] = v;
@@ -830,7 +852,8 @@ int launch_fparam(const double* lam_m, const double* lam_var, const double* r, i
   template int launch_reduce_slices<R, R>(const R*, int64_t, int, R*, int64_t, hipStream_t);                        \
   template int launch_metric_contract<R>(const Theta&, const int*, int, int, int, const R*, int64_t, const R*,      \
                                          int64_t, double*, hipStream_t);                                            \
-  template int launch_add_diag<R>(R*, int64_t, int, double, hipStream_t);
+  template int launch_add_diag<R>(R*, int64_t, int, double, hipStream_t);                                           \
+  template int launch_axpby_block<R>(R*, int64_t, const R*, int64_t, int, int, double, double, hipStream_t);
 GP_INST(double)
 GP_INST(float)
 #undef GP_INST

@@ -146,6 +146,49 @@ int potrf_rec(const CholBufsT<R>& B, int r0, int n, bool need_inv, hipStream_t s
 template int potrf_rec<double>(const CholBufsT<double>&, int, int, bool, hipStream_t);
 template int potrf_rec<float>(const CholBufsT<float>&, int, int, bool, hipStream_t);
 
+// ------------------------------------------------------------------ two-sided triangular product
+// Wout (lower) = 1/2 Li^T Q Li on the n x n diagonal block at r0, Q symmetric (stored in full),
+// Li lower triangular.  The direct route R = Q Li, W = Li^T R costs 4/3 n^3; splitting once,
+//   Li = [A 0; B C],  H = Q21 A + 1/2 Q22 B,
+//   W11 = A^T Q11 A + B^T H + H^T B,   W21 = C^T (H + 1/2 Q22 B),   W22 = C^T Q22 C,
+// costs 3/4 n^3 plus the two half-size products (LAPACK's sygst idea), i.e. 13/12 n^3 with
+// one level.  Z and H are n x n scratch matrices with the same leading dimension.
+template <typename R>
+struct TwoSidedBufs {
+  const R* Q; const R* Li; R* W; R* Z; R* H; int64_t ld; int min_split;
+};
+template <typename R>
+static int two_sided(const TwoSidedBufs<R>& b, int r0, int n, hipStream_t s) {
+  const int64_t ld = b.ld;
+  auto at = [&](const R* base, int r, int c) { return const_cast<R*>(base) + (int64_t)r * ld + c; };
+  const int k = n / TILE;
+  if (n < b.min_split || k < 2) {
+    GP_TRY(gemm<R>(s, 1, 1, n, n, n, 1.0, at(b.Q, r0, r0), ld, at(b.Li, r0, r0), ld, 0.0, at(b.Z, r0, r0), ld, 0, 0, 1, /*walk=*/2));
+    GP_TRY(gemm<R>(s, 1, 1, n, n, n, 0.5, at(b.Li, r0, r0), ld, at(b.Z, r0, r0), ld, 0.0, at(b.W, r0, r0), ld, 1, 2, 0, /*walk=*/1));
+    return 0;
+  }
+  const int n1 = ((k + 1) / 2) * TILE, n2 = n - n1, r1 = r0 + n1;
+  R* Z21 = at(b.Z, r1, r0);
+  R* H21 = at(b.H, r1, r0);
+  // Z21 = 1/2 Q22 B
+  GP_TRY(gemm<R>(s, 1, 1, n2, n1, n2, 0.5, at(b.Q, r1, r1), ld, at(b.Li, r1, r0), ld, 0.0, Z21, ld, 0, 0, 0));
+  // H = Q21 A + Z21
+  GP_HIP(hipMemcpy2DAsync(H21, (size_t)ld * sizeof(R), Z21, (size_t)ld * sizeof(R), (size_t)n1 * sizeof(R), (size_t)n2,
+                          hipMemcpyDeviceToDevice, s));
+  GP_TRY(gemm<R>(s, 0, 1, n2, n1, n1, 1.0, at(b.Q, r1, r0), ld, at(b.Li, r0, r0), ld, 1.0, H21, ld, 0, 0, 1, /*walk=*/2));
+  // Z21 = H + 1/2 Q22 B ;  W21 = 1/2 C^T Z21
+  GP_TRY(launch_axpby_block<R>(Z21, ld, H21, ld, n2, n1, 1.0, 1.0, s));
+  static const int w21_walk = getenv("GPFIT_W21_WALK") ? atoi(getenv("GPFIT_W21_WALK")) : 0;
+  GP_TRY(gemm<R>(s, 1, 1, n2, n1, n2, 0.5, at(b.Li, r1, r1), ld, Z21, ld, 0.0, at(b.W, r1, r0), ld, 0, 2, 0, w21_walk));
+  // W11 = 1/2 A^T Q11 A + 1/2 (B^T H + H^T B)   (lower tiles)
+  GP_TRY(two_sided<R>(b, r0, n1, s));
+  GP_TRY(gemm<R>(s, 1, 1, n1, n1, n2, 0.5, at(b.Li, r1, r0), ld, H21, ld, 1.0, at(b.W, r0, r0), ld, 1, 0, 0));
+  GP_TRY(gemm<R>(s, 1, 1, n1, n1, n2, 0.5, H21, ld, at(b.Li, r1, r0), ld, 1.0, at(b.W, r0, r0), ld, 1, 0, 0));
+  // W22 = 1/2 C^T Q22 C
+  GP_TRY(two_sided<R>(b, r1, n2, s));
+  return 0;
+}
+
 // ------------------------------------------------------------------ host pieces of localker
 static double lin_pm1_host(int i, int n) {
   if (n <= 1) return -1.0;
@@ -302,14 +345,17 @@ static int fit_eval_impl(gpfit_ctx* c, void* stream, const double* theta, const 
   if (want_grad) {
     // W = 1/2 (K~^-1 - K~^-1 V K~^-1) = 1/2 Li^T (I - T T^T) Li        (T = L^-1 L_V)
     //   Q = I - T T^T   lower x upper, lower tiles only          N^3/3
-    //   R = Q Li        symmetric x lower                         N^3
-    //   W = 1/2 Li^T R  upper x dense, lower tiles only          N^3/3
+    //   W = 1/2 Li^T Q Li  two-sided product (two_sided above)   13/12 N^3 with one split
+    //                      (direct: R = Q Li, W = 1/2 Li^T R     4/3 N^3)
     GP_TRY(gemm<R>(s, 0, 0, np, np, np, -1.0, RP(c->Tbuf), ld, RP(c->Tbuf), ld, 0.0, RP(c->Wbuf), ld, 1, 1, 2, /*reverse=*/1));
     GP_TRY(launch_add_diag(RP(c->Wbuf), ld, np, 1.0, s));
     GP_TRY(launch_symmetrize(RP(c->Wbuf), ld, np, s));
-    GP_TRY(gemm<R>(s, 1, 1, np, np, np, 1.0, RP(c->Wbuf), ld, RP(c->Libuf), ld, 0.0, RP(c->Zbuf), ld, 0, 0, 1, /*walk=*/2));
-    GP_TRY(gemm<R>(s, 1, 1, np, np, np, 0.5, RP(c->Libuf), ld, RP(c->Zbuf), ld, 0.0, RP(c->Wbuf), ld, 1, 2, 0, /*walk=*/1));
-    GP_TRY(launch_adjoint(RP(c->Wbuf), RP(c->Cos), ld, RP(c->bv), RP(c->q), n, np, RP(c->Abuf), c->upart, c->vpart, c->sumA_part, s));
+    {
+      static const int ts_min = getenv("GPFIT_TS_MIN") ? atoi(getenv("GPFIT_TS_MIN")) : 4096;
+      TwoSidedBufs<R> tb{RP(c->Wbuf), RP(c->Libuf), RP(c->Tbuf), RP(c->Zbuf), RP(c->Tmp), ld, ts_min > 0 ? ts_min : (1 << 30)};
+      GP_TRY(two_sided<R>(tb, 0, np, s));
+    }
+    GP_TRY(launch_adjoint(RP(c->Tbuf), RP(c->Cos), ld, RP(c->bv), RP(c->q), n, np, RP(c->Abuf), c->upart, c->vpart, c->sumA_part, s));
     const int t64 = np / 64;
     GP_TRY(launch_adjoint_reduce(c->upart, c->vpart, c->sumA_part, t64, t64 * (t64 + 1) / 2, RP(c->q), RP(c->wl), n, np,
                                  RP(c->tvec), c->rpad, c->scal + 7, s));
