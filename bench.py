@@ -55,8 +55,8 @@ def host_cores() -> int:
     return max(1, min(n, 32))
 
 
-def profiled_traffic():
-    """HBM bytes per launch of the largest dgemm launch, from the committed PMC passes
+def profiled_traffic(kernel_name):
+    """HBM bytes per launch of the named kernel, from the committed PMC passes
     (profiles/r*_summary.json: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE of this same
     command, FETCH_SIZE doubled per the gfx950 correction).  PMC collection needs its own
     profiler runs, so this is read from the tracked profile, not measured live; None if absent."""
@@ -68,7 +68,10 @@ def profiled_traffic():
         rows = json.load(open(files[-1])).get("hbm_traffic_by_kernel") or []
         if not rows:
             return None
-        r = rows[0]
+        match = [x for x in rows if kernel_name in x["kernel"]]
+        if not match:
+            return None
+        r = max(match, key=lambda x: x["fetch_corrected_GB_per_launch"])
         return {"unit": "GB/launch", "kernel": r["kernel"], "blocks": r["blocks"],
                 "fetch_corrected": round(r["fetch_corrected_GB_per_launch"], 3),
                 "write": round(r["write_GB_per_launch"], 3), "source": os.path.basename(files[-1])}
@@ -215,19 +218,20 @@ def main():
         prof = eng.get_profile()
         eng.set_profile(False)
         gemm_tflops = prof["gemm_flops"] / (prof["gemm_ms"] * 1e-3) / 1e12 if prof["gemm_ms"] > 0 else 0.0
-        # dominant kernel = the single largest launch: R = Q L^-1 (Q symmetric N x N, L^-1 lower
-        # triangular), algorithmic flops N^3; one call per fit, so the
-        # rocprofv3 kernel_stats row of gemm_mfma_kernel<double,true,true,false,128> is its average.
+        # dominant kernel = the single largest launch: T = L^-1 L_V (both operands lower triangular,
+        # lower output; algorithmic flops N^3/3), the stream-K kernel
+        # gemm_streamk_kernel<R,false,true>: one call per fit, so its rocprofv3 kernel_stats row is
+        # its average (the event bracket here also covers the ~2 % fix-up kernel behind it).
         npad = -(-N // 128) * 128
-        dom_flops = float(npad) ** 3
+        dom_flops = float(npad) ** 3 / 3.0
         dom_tflops = dom_flops / max(prof["largest_gemm_ms"], 1e-9) / 1e9
+        dom_name = "gemm_streamk_kernel<%s, false, true>" % ("double" if args.dtype == "f64" else "float")
         roofline = {
             "bound": "mfma",
-            "kernel": "gemm_mfma_kernel<%s,true,true,false,128> (R = Q L^-1, N^3 flops, 1 launch/fit; %s)"
-                      % ("double" if args.dtype == "f64" else "float",
-                         "v_mfma_f64_16x16x4_f64" if args.dtype == "f64" else "v_mfma_f32_16x16x4_f32"),
+            "kernel": dom_name + " (T = L^-1 L_V, N^3/3 flops, 1 launch/fit; %s)"
+                      % ("v_mfma_f64_16x16x4_f64" if args.dtype == "f64" else "v_mfma_f32_16x16x4_f32"),
             "achieved": round(dom_tflops, 2), "peak": peak, "unit": "TFLOP/s",
-            "frac": round(dom_tflops / peak, 4), "traffic": profiled_traffic() if args.dtype == "f64" else None,
+            "frac": round(dom_tflops / peak, 4), "traffic": profiled_traffic(dom_name) if args.dtype == "f64" else None,
             "launches_per_fit": 1, "avg_launch_ms": round(prof["largest_gemm_ms"], 4),
             "algorithmic_flops_per_launch": dom_flops,
             "gemm_family": {"what": "all 128-tile GEMM/SYRK/TRSM/TRTRI launches (gemm_mfma_kernel<..,128> + gemm_streamk_kernel), executed flops",

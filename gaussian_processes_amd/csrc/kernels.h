@@ -88,6 +88,10 @@ template <typename R>
 int launch_axpby_block(R* dst, int64_t ldd, const R* src, int64_t lds, int rows, int cols, double a, double b,
                        hipStream_t s);
 
+// active-learning utility of nstar candidates (utils.py:413-525), r = list of response counts
+int launch_nd_utility(const double* sigma2, const double* mu, int64_t nstar, const double* r, int nr, double* U,
+                      hipStream_t s);
+
 // ---- helpers of the general (materialising) acosker / localker entry points
 int launch_pad_copy(const double* src, int64_t lds, int rows, int cols, double* dst, int64_t ldd, int prow,
                     int pcol, hipStream_t s);

@@ -558,6 +558,28 @@ def print_hyp(theta):
         print(f' {key:<12}: {_scalar(theta[key]):>8.4f}{extra}')
 
 
+# ------------------------------------------------------------------ active-learning utility (utils.py:413-525)
+@torch.no_grad()
+def nd_utility(sigma2, mu, r_masked):
+    """Utility U = H(r|x,D) - <H(r|f,x)> of each candidate stimulus (reference utils.py:498-525
+    with nd_p_r_given_xD / nd_lambda_r_mean / nd_mean_noise_entropy, 413-496).  ``sigma2`` and ``mu``
+    are the variance and mean of log f for the candidates (0-d or [nstar]); ``r_masked`` the response
+    counts of the truncated sum (the notebooks pass ``arange(0, 100)``).  One fused device kernel,
+    Lambert W included (the reference goes through scipy on the host, utils.py:464-466)."""
+    lib = _lib.load()
+    s2, m = _cu(sigma2), _cu(mu)
+    if s2.ndim == 0:                                     # utils.py:509-511
+        s2, m = s2[None], m[None]
+    s2, m = s2.reshape(-1).contiguous(), m.reshape(-1).contiguous()
+    if s2.numel() != m.numel():
+        raise ValueError("nd_utility: sigma2 and mu must have the same number of entries")
+    r = _cu(r_masked).reshape(-1).contiguous()
+    U = torch.empty_like(s2)
+    _lib.check(lib.gpfit_nd_utility(_stream(), s2.data_ptr(), m.data_ptr(), s2.numel(), r.data_ptr(), r.numel(),
+                                    U.data_ptr()), "gpfit_nd_utility")
+    return U
+
+
 # ------------------------------------------------------------------ metric (utils.py:1502-1541)
 def explained_variance(rtst, f_pred, sigma=True):
     """Reliability-normalised r^2 between predicted rates and repeated test responses

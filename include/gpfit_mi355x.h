@@ -131,13 +131,22 @@ int gpfit_fparam_eval(gpfit_ctx* ctx, void* stream, const double* lam_m, const d
                       const double* r, int64_t N, double logA, int closed_form_lambda0, double lambda0_in,
                       double* f_out, double* out_host);
 
+/* Active-learning utility of nstar candidate stimuli, U = H(r|x,D) - <H(r|f,x)>
+ * (nd_utility with nd_p_r_given_xD, nd_lambda_r_mean, nd_mean_noise_entropy, utils.py:413-525;
+ * call site one_cell_active_training.ipynb: u2d = nd_utility(logf_var, logf_mean, arange(100))).
+ * sigma2, mu: device [nstar] (variance and mean of log f); r: device [nr] response counts;
+ * U: device [nstar].  The principal-branch Lambert W (scipy on the host in the reference,
+ * utils.py:464-466) is evaluated on the device.  Asynchronous on `stream`. */
+int gpfit_nd_utility(void* stream, const double* sigma2, const double* mu, int64_t nstar, const double* r,
+                     int nr, double* U);
+
 /* Per-launch HIP-event timing of the dominant kernels during gpfit_fit_eval (bench.py's
  * roofline leg; adds two event records per launch, so leave it off when timing throughput).
  * out16: 0 sum of the 128-tile GEMM launch durations [ms] (the dominant kernel family, stream-K
  *        variant included), 1 flops those launches executed, 2 #launches, 3 sum of Cholesky-leaf
  *        durations [ms], 4 #leaves, 5 Gram kernel [ms], 6 its flops, 7 #, 8-10 the same three
  *        figures for the 64/32-tile instances, 11-12 duration [ms] and flops of the single largest
- *        GEMM launch (Q L^-1 at the headline), 13-15 unused. */
+ *        GEMM launch (L^-1 L_V at the headline), 13-15 unused. */
 int gpfit_set_profile(gpfit_ctx* ctx, int on);
 int gpfit_get_profile(gpfit_ctx* ctx, double* out16);
 /* Host milliseconds the last gpfit_fit_eval spent enqueuing work (before its final sync). */

@@ -472,6 +472,52 @@ def predict_cholesky(theta, xstar, x, C, Kt, m, V):
     return mu, s2
 
 
+# ------------------------------------------------------------- active-learning utility
+def lambert_w0(z: torch.Tensor) -> torch.Tensor:
+    """Principal branch of the Lambert W function for real z >= 0 (the reference calls
+    scipy.special.lambertw(z, k=0, tol=1e-8) and keeps the real part, utils.py:464-466):
+    logarithmic starting value + Fritsch's quartic iteration on w = ln(z / w)."""
+    z = z.to(torch.float64)
+    w = torch.where(z < 2.0, z / (1.0 + z), torch.log(z.clamp_min(2.0)) - torch.log(torch.log(z.clamp_min(2.0))))
+    pos = z > 0
+    zs = torch.where(pos, z, torch.ones_like(z))
+    w = torch.where(pos, w, torch.ones_like(w))
+    for _ in range(6):
+        zn = torch.log(zs / w) - w
+        q = 2.0 * (1.0 + w) * (1.0 + w + 2.0 / 3.0 * zn)
+        eps = zn / (1.0 + w) * (q - zn) / (q - 2.0 * zn)
+        w = w * (1.0 + eps)
+    return torch.where(pos, w, torch.zeros_like(w))
+
+
+def utility_terms(sigma2, mu, r):
+    """p(r|x,D) of the Laplace approximation and its log for r in the given list
+    (nd_lambda_r_mean + nd_p_r_given_xD, utils.py:438-496), incl. the reference's treatment of
+    overflowing terms: where exp(r sigma2 + mu) sigma2 is inf, z, r sigma2, r and log r! are set
+    to 0 (the term still enters the sums).  Shapes (nr, nstar)."""
+    sigma2, mu, r = _t(sigma2).reshape(-1), _t(mu).reshape(-1), _t(r).reshape(-1)
+    rs = torch.outer(r, sigma2)
+    z = torch.exp(rs + mu) * sigma2[None, :]
+    keep = z != float("inf")
+    z = torch.where(keep, z, torch.zeros_like(z))
+    rs = torch.where(keep, rs, torch.zeros_like(rs))
+    lam = rs + mu - lambert_w0(z)                                    # utils.py:466
+    e = torch.exp(lam)
+    lrf = torch.where(keep, torch.lgamma(r + 1.0)[:, None].expand_as(z), torch.zeros_like(z))
+    rr = torch.where(keep, r[:, None].expand_as(z), torch.zeros_like(z))
+    logp = lam * rr - e - (lam - mu) ** 2 / (2.0 * sigma2[None, :]) - 0.5 * guarded_log(e * sigma2 + 1.0) - lrf  # 494
+    return torch.exp(logp), logp, lrf
+
+
+def active_utility(sigma2, mu, r):
+    """U = H(r|x,D) - <H(r|f,x)> (nd_utility, utils.py:498-525; nd_mean_noise_entropy 413-430)."""
+    sigma2, mu = _t(sigma2).reshape(-1), _t(mu).reshape(-1)
+    p, logp, lrf = utility_terms(sigma2, mu, r)
+    H_r = -(p * logp).sum(0)
+    H_mean = -torch.exp(mu + 0.5 * sigma2) * (mu + sigma2 - 1.0) + (p * lrf).sum(0)
+    return H_r - H_mean
+
+
 # ------------------------------------------------------------- synthetic workload
 def default_limits():
     """generate_theta's boxes (utils.py:854-855)."""

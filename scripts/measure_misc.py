@@ -64,3 +64,26 @@ for rep in range(3):
     rc = lib.gpfit_estep(eng._ctx, gp._stream(), K.data_ptr(), K.stride(0), N, r.data_ptr(), m.data_ptr(), f.data_ptr(),
                          syn.F_PARAMS["logA"], m_new.data_ptr(), V_new.data_ptr(), V_new.stride(0))
     torch.cuda.synchronize(); print(f"gpfit_estep N={N}: rc={rc} {1e3*(time.time()-t0):.2f} ms  ({2.667*N**3/(time.time()-t0)/1e12:.1f} TFLOP/s on 2.67 N^3)", flush=True)
+
+# (4) one active-learning scoring step: 3000 candidates against N=4096 inducing points
+N, d, ns = 4096, 256, 3000
+grid = syn.grid_for(d)
+th = tth(syn.theta_eval())
+X = torch.from_numpy(syn.stimuli(N, d)).to(dev)
+Xs = torch.from_numpy(np.random.default_rng(3).standard_normal((ns, d))).to(dev)
+C, mask = gp.localker(th, upper, lower, grid)
+Kt = gp.acosker(th, X, X, C=C)
+r_np, m_np = syn.cell_inputs(N)
+m = torch.from_numpy(m_np).to(dev); V = 0.5 * Kt
+A, lam0 = float(np.exp(syn.F_PARAMS["logA"])), syn.F_PARAMS["lambda0"]
+rr = torch.arange(0, 100, dtype=torch.float64, device=dev)
+Kt_inv = gp.spd_inverse(Kt)          # model state in the notebook (K_tilde_inv_b), not part of the scoring step
+for rep in range(3):
+    torch.cuda.synchronize(); t0 = time.time()
+    Kvec_s = gp.acosker(th, Xs, x2=None, C=C, dC=None, diag=True)
+    K_s = gp.acosker(th, Xs, x2=X, C=C, dC=None, diag=False)
+    mu, s2 = gp.lambda_moments(Xs, Kt, gp.matmul(K_s, Kt_inv), Kvec_s, K_s, C, m, V, th)
+    torch.cuda.synchronize(); t1 = time.time()
+    u = gp.nd_utility(A ** 2 * s2, A * mu + lam0, rr)
+    best = int(u.argmax()); torch.cuda.synchronize(); t2 = time.time()
+    print(f"active-learning scoring, {ns} candidates x N={N}: kernel rows + lambda moments {1e3*(t1-t0):.2f} ms, utility+argmax {1e3*(t2-t1):.3f} ms, best {best}", flush=True)

@@ -286,8 +286,29 @@ def g6(tol, name, dup=0):
     ref.EIGVAL_TOL = 1e-4
 
 
+def g8():
+    """Active-learning utility (utils.py:413-525): nd_utility on batches of (sigma2, mu) with the
+    notebook's r = arange(100) (one_cell_active_training.ipynb), incl. entries whose
+    exp(r sigma2 + mu) overflows (masked terms) and the 0-d call form."""
+    rng = np.random.default_rng(8)
+    n = 96
+    sigma2 = np.concatenate([rng.uniform(0.005, 2.5, n - 8), [1e-6, 1e-3, 4.0, 7.5, 9.0, 12.0, 30.0, 0.3]])
+    mu = np.concatenate([rng.uniform(-6.0, 2.0, n - 8), [-2.0, 0.5, 1.0, -1.0, 0.2, -3.0, -0.5, 3.5]])
+    r = torch.arange(0, 100, dtype=torch.float64)
+    U = ref.nd_utility(torch.from_numpy(sigma2), torch.from_numpy(mu), r)
+    p, logp, r2d, lrf = ref.nd_p_r_given_xD(r, torch.from_numpy(sigma2), torch.from_numpy(mu))
+    U0 = ref.nd_utility(torch.tensor(0.37), torch.tensor(-1.1), r)
+    r_short = torch.arange(0, 17, dtype=torch.float64)
+    U_short = ref.nd_utility(torch.from_numpy(sigma2), torch.from_numpy(mu), r_short)
+    save("g8_nd_utility.npz", sigma2=sigma2, mu=mu, r=r.numpy(), U=U.numpy(), p=p.numpy(), logp=logp.numpy(),
+         U_scalar=U0.numpy(), sigma2_scalar=0.37, mu_scalar=-1.1, r_short=r_short.numpy(), U_short=U_short.numpy())
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "g8":
+        g8()
+        sys.exit(0)
     g1()
     g2()
     g3()
@@ -295,3 +316,4 @@ if __name__ == "__main__":
     g5()
     g6(1e-14, "g6_vargp_full_N128.npz")
     g6(1e-4, "g6_vargp_trunc_N128.npz", dup=16)
+    g8()

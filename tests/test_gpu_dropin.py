@@ -197,3 +197,58 @@ def test_vargp_end_to_end_matches_reference(gp, name, tol_track):
     for key in ("fit_parameters", "final_kernel", "err_dict", "xtilde", "hyperparams_tuple", "f_params", "m_b", "V_b",
                 "C", "mask", "K_tilde_b", "K_tilde_inv_b", "K_b", "Kvec", "B", "values_track"):
         assert key in fit
+
+
+def test_nd_utility_matches_reference(gp):
+    """Active-learning utility: device kernel incl. Lambert W against the real
+    reference's nd_utility (scipy Lambert W) on the G8 fixture -- values from 7e-8 to 6e7, entries
+    whose exp() overflows, the 0-d call form and a shorter r list -- and against the oracle on a
+    batch of the size the notebook scores (a few thousand candidates x r = 0..99)."""
+    g = load_golden("g8_nd_utility.npz")
+    U = gp.nd_utility(T(g["sigma2"]), T(g["mu"]), T(g["r"])).cpu().numpy()
+    assert np.max(np.abs(U - g["U"]) / np.abs(g["U"])) < 1e-9
+    U0 = gp.nd_utility(torch.tensor(float(g["sigma2_scalar"])), torch.tensor(float(g["mu_scalar"])), T(g["r"]))
+    assert U0.shape == (1,) and abs(float(U0) - float(g["U_scalar"][0])) < 1e-12
+    Us = gp.nd_utility(T(g["sigma2"]), T(g["mu"]), T(g["r_short"])).cpu().numpy()
+    assert np.max(np.abs(Us - g["U_short"]) / np.abs(g["U_short"])) < 1e-9
+    rng = np.random.default_rng(5)
+    s2, mu = rng.uniform(1e-3, 3.0, 3000), rng.uniform(-7.0, 2.5, 3000)
+    r = np.arange(100, dtype=np.float64)
+    Ub = gp.nd_utility(T(s2), T(mu), T(r)).cpu().numpy()
+    Uo = orc.active_utility(s2, mu, r).numpy()
+    assert np.max(np.abs(Ub - Uo) / np.maximum(np.abs(Uo), 1e-6)) < 1e-9
+    assert int(np.argmax(Ub)) == int(np.argmax(Uo))          # the stimulus the loop would pick
+
+
+def test_active_learning_scoring_step(gp):
+    """One scoring step of the closed loop as the notebook writes it
+    (one_cell_active_training.ipynb: acosker(diag) + acosker(x*, xtilde) + K@B + lambda_moments +
+    nd_utility + argmax) through the drop-in functions, against the oracle on the same inputs."""
+    g = load_golden("g5_predict_N64.npz")
+    th = tth(g["theta"])
+    C, mask = gp.localker(th, UPPER, LOWER, 8)
+    X = T(g["X"])[:, mask].contiguous()
+    rng = np.random.default_rng(11)
+    Xs = T(rng.standard_normal((200, g["X"].shape[1])))[:, mask].contiguous()
+    Kt = gp.acosker(th, X, X, C=C)
+    ev, B = torch.linalg.eigh(Kt)
+    Kt_b, Kt_inv_b = torch.diag(ev), torch.diag(1 / ev)
+    m_b = gp.matmul(B, T(g["m"]), transA=True)
+    V_b = gp.matmul(B, gp.matmul(T(g["V"]), B), transA=True)
+    A, lambda0 = float(np.exp(g["logA"])), float(g["lambda0"])
+    Kvec = gp.acosker(th, Xs, x2=None, C=C, dC=None, diag=True)
+    K = gp.acosker(th, Xs, x2=X, C=C, dC=None, diag=False)
+    K_b = gp.matmul(K, B)
+    lam_m, lam_var = gp.lambda_moments(Xs, Kt_b, gp.matmul(K_b, Kt_inv_b), Kvec, K_b, C, m_b, V_b, th)
+    r = torch.arange(0, 100, dtype=torch.float64)
+    u = gp.nd_utility(A ** 2 * lam_var, A * lam_m + lambda0, r)
+    # oracle: same chain on the CPU
+    thc = {k: float(v) for k, v in zip(KEYS, g["theta"])}
+    Cc, maskc = orc.spatial_metric(thc, LOWER, UPPER, 8)
+    Xc, Xsc = torch.from_numpy(g["X"])[:, maskc], Xs.cpu()
+    mu_o, s2_o = orc.predict_cholesky(thc, Xsc, Xc, Cc, orc.arccos_gram(thc, Xc, Xc, Cc), torch.from_numpy(g["m"]),
+                                      torch.from_numpy(g["V"]))
+    u_o = orc.active_utility(A ** 2 * s2_o, A * mu_o + lambda0, r)
+    assert relerr(lam_m.cpu().numpy(), mu_o.numpy()) < 1e-8 and relerr(lam_var.cpu().numpy(), s2_o.numpy()) < 1e-7
+    assert relerr(u.cpu().numpy(), u_o.numpy()) < 1e-6
+    assert int(u.argmax()) == int(u_o.argmax())

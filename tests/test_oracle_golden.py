@@ -226,3 +226,16 @@ def test_logdet_fallback_paths():
         assert float(orc.chol_logdet(A)) == 0.0
     with pytest.raises(ValueError):
         orc.guarded_log(T([1e-12]))
+
+
+def test_g8_active_utility():
+    """oracle.active_utility (own Lambert W) against the reference's nd_utility (scipy Lambert W),
+    incl. the overflow-masked terms, the 0-d call and a shorter r list."""
+    g = load_golden("g8_nd_utility.npz")
+    U = orc.active_utility(g["sigma2"], g["mu"], g["r"]).numpy()
+    assert relerr(U, g["U"]) < 1e-12
+    assert np.max(np.abs(U - g["U"]) / np.abs(g["U"])) < 1e-10      # element-wise, spans 1e-8 .. 1e7
+    p, logp, _ = orc.utility_terms(g["sigma2"], g["mu"], g["r"])
+    assert np.max(np.abs(logp.numpy() - g["logp"])) < 1e-11
+    assert abs(float(orc.active_utility(float(g["sigma2_scalar"]), float(g["mu_scalar"]), g["r"])) - float(g["U_scalar"][0])) < 1e-13
+    assert np.max(np.abs(orc.active_utility(g["sigma2"], g["mu"], g["r_short"]).numpy() - g["U_short"]) / np.abs(g["U_short"])) < 1e-10
