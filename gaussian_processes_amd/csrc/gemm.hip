@@ -7,11 +7,15 @@
 
 namespace gpfit {
 
-template <typename R, bool A_KMAJOR, bool B_KMAJOR, bool EDGE, int T>
-__global__ __launch_bounds__(GEMM_THREADS, (T == 128 ? 2 : 4)) void gemm_mfma_kernel(GemmArgsT<R> p, int tiles_n,
-                                                                                     int ntiles) {
+// NS = LDS stages of the main loop (gemm_core.h): 2 everywhere except the "deep" small-tile
+// instances (4 at T = 64, 8 at T = 32) the launcher picks when a launch has at most two
+// workgroups per CU, i.e. when nothing else hides the load latency.
+template <typename R, bool A_KMAJOR, bool B_KMAJOR, bool EDGE, int T, int NS = 2>
+__global__ __launch_bounds__(GEMM_THREADS, (T == 128 || NS > 2 ? 2 : 4)) void gemm_mfma_kernel(GemmArgsT<R> p,
+                                                                                               int tiles_n,
+                                                                                               int ntiles) {
   constexpr int KT = Real<R>::KT;
-  __shared__ __attribute__((aligned(16))) R smem[4 * KT * T];
+  __shared__ __attribute__((aligned(16))) R smem[2 * NS * KT * T];
 
   // heaviest tiles first: with triangular operands the k range depends on the tile position,
   // so the launcher asks for the walk that starts with the long ones (shorter tail):
@@ -55,7 +59,7 @@ __global__ __launch_bounds__(GEMM_THREADS, (T == 128 ? 2 : 4)) void gemm_mfma_ke
 #pragma unroll
     for (int j = 0; j < T / 32; ++j) acc[i][j] = acc_zero<R>();
 
-  gemm_mainloop<R, A_KMAJOR, B_KMAJOR, EDGE, T>(A, p.lda, B, p.ldb, p.M, p.N, row0, col0, kbeg, kend, smem, acc);
+  gemm_mainloop<R, A_KMAJOR, B_KMAJOR, EDGE, T, 0, NS>(A, p.lda, B, p.ldb, p.M, p.N, row0, col0, kbeg, kend, smem, acc);
 
   const R alpha = (R)p.alpha, beta = (p.split_k > 1) ? (R)0 : (R)p.beta;
   const int64_t ldc = p.ldc;
@@ -98,8 +102,14 @@ static void launch_T(const GemmArgsT<R>& p, hipStream_t s) {
   const bool edge = (p.M % T) || (p.N % T) || (p.out_lower && (p.M % TILE));
   dim3 grid(p.tile_limit > 0 ? std::min(p.tile_limit, tiles) : tiles, p.batch, p.split_k > 1 ? p.split_k : 1);
   dim3 block(GEMM_THREADS);
-#define GP_LAUNCH(AK, BK, ED) \
-  hipLaunchKernelGGL((gemm_mfma_kernel<R, AK, BK, ED, T>), grid, block, 0, s, p, tn, tiles)
+  constexpr int DEEP = (T == 128) ? 2 : (T == 64 ? 4 : 8);
+  static const int deep_max = getenv("GPFIT_DEEP_MAX") ? atoi(getenv("GPFIT_DEEP_MAX")) : 512;  // tuning knob
+  const bool deep = DEEP > 2 && !edge && (long)grid.x * grid.y * grid.z <= deep_max;
+#define GP_LAUNCH(AK, BK, ED)                                                                          \
+  do {                                                                                                 \
+    if (deep) hipLaunchKernelGGL((gemm_mfma_kernel<R, AK, BK, ED, T, (ED ? 2 : DEEP)>), grid, block, 0, s, p, tn, tiles); \
+    else hipLaunchKernelGGL((gemm_mfma_kernel<R, AK, BK, ED, T, 2>), grid, block, 0, s, p, tn, tiles); \
+  } while (0)
   const int sel = (p.a_kmajor ? 4 : 0) | (p.b_kmajor ? 2 : 0) | (edge ? 1 : 0);
   switch (sel) {
     case 0: GP_LAUNCH(false, false, false); break;

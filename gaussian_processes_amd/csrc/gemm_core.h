@@ -246,9 +246,20 @@ template <typename R, bool KMAJOR, int T> struct TileDma {
   __device__ __forceinline__ void advance() { base += step; }
 };
 
+// Wait until at most N of this wave's DMA instructions are outstanding and all its LDS reads have
+// returned, then the workgroup barrier (a raw s_barrier: __syncthreads() would drain every DMA).
+template <int N> __device__ __forceinline__ void dma_wait_barrier() {
+  asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory");
+}
+
 // ABL: ablation bits for scripts/dev_gemm_abl.hip only (1 no barrier, 2 no DMA in the loop);
 // product code uses 0.
-template <typename R, bool A_KMAJOR, bool B_KMAJOR, bool EDGE, int T, int ABL = 0>
+// NS = LDS stages (each one A tile + one B tile); the DMA runs NS-1 tiles ahead of the MFMAs.
+// NS = 2 for the 128-tile (two co-resident workgroups hide each other's latency); the small-tile
+// instances, used exactly when a launch cannot fill the chip, run one workgroup per CU and need
+// several tiles in flight to cover the L2 / fabric latency (NS = 4 at T = 64, 8 at T = 32).
+// smem: 2 * NS * KT * T elements.
+template <typename R, bool A_KMAJOR, bool B_KMAJOR, bool EDGE, int T, int ABL = 0, int NS = 2>
 __device__ __forceinline__ void gemm_mainloop(const R* __restrict__ A, int64_t lda, const R* __restrict__ B,
                                               int64_t ldb, int M, int N, int row0, int col0, int kbeg, int kend,
                                               R* smem, typename Real<R>::acc_t (&acc)[T / 32][T / 32]) {
@@ -257,6 +268,9 @@ __device__ __forceinline__ void gemm_mainloop(const R* __restrict__ A, int64_t l
     return;
   } else {
     constexpr int MI = T / 32, WT = T / 2, KT = Real<R>::KT, LT = KT * T, NKK = KT / 4;
+    constexpr int D = NS - 1;         // prefetch distance in tiles
+    constexpr int OPS = 2 * MI;       // DMA instructions per wave per tile
+    static_assert(NS >= 2 && (D - 1) * OPS < 64, "vmcnt is a 6-bit counter");
     using Img = LdsImage<R, T>;
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -267,6 +281,7 @@ __device__ __forceinline__ void gemm_mainloop(const R* __restrict__ A, int64_t l
     kbeg = __builtin_amdgcn_readfirstlane(kbeg);
     kend = __builtin_amdgcn_readfirstlane(kend);
     if (kbeg >= kend) return;
+    const int ntile = (kend - kbeg) / KT;
 
     TileDma<R, A_KMAJOR, T> da;
     TileDma<R, B_KMAJOR, T> db;
@@ -274,17 +289,26 @@ __device__ __forceinline__ void gemm_mainloop(const R* __restrict__ A, int64_t l
     db.init(B, ldb, col0, kbeg, wave, lane);
     const uint32_t lds0 = (uint32_t)(uintptr_t)smem;  // low 32 bits of a generic LDS pointer = LDS address
     constexpr uint32_t LTB = LT * sizeof(R);
+    auto issue = [&](int stage) {
+      const uint32_t img = lds0 + (uint32_t)stage * 2u * LTB;
+      da.issue(img);
+      db.issue(img + LTB);
+      da.advance();
+      db.advance();
+    };
 
-    __syncthreads();  // a previous tile's readers (stream-K) are done with both buffers
-    da.issue(lds0);
-    db.issue(lds0 + LTB);
-    __syncthreads();  // vmcnt(0): the DMA of every wave has landed
+    __syncthreads();  // a previous tile's readers (stream-K) are done with every stage
+#pragma unroll
+    for (int t = 0; t < D; ++t)
+      if (t < ntile) issue(t);
+    if (ntile >= D) dma_wait_barrier<(D - 1) * OPS>();  // tile 0 of every wave has landed
+    else dma_wait_barrier<0>();
 
     // MFMA fragments are double-buffered in registers across the kk sub-steps: the ds_reads of
     // sub-step kk+1 are issued BEFORE the 16 MFMAs of sub-step kk.  The single barrier of a K
     // step sits before the MFMAs of the last sub-step and is followed by the first fragment
-    // reads of the next buffer, so both waits are covered by those MFMAs; the DMA of the next
-    // tile is issued at the top of the step (its buffer's readers passed the previous barrier).
+    // reads of the next stage, so both waits are covered by those MFMAs; the DMA of tile s+D is
+    // issued at the top of step s into the stage step s-1 read (its readers passed that barrier).
     R fa[2][MI], fb[2][MI];
     auto frag = [&](const R* S, int kk, R (&a)[MI], R (&b)[MI]) {
       const int k = kk * 4 + fk;
@@ -296,25 +320,24 @@ __device__ __forceinline__ void gemm_mainloop(const R* __restrict__ A, int64_t l
     };
     frag(smem, 0, fa[0], fb[0]);
 
-    int buf = 0;
-    for (int k0 = kbeg; k0 < kend; k0 += KT) {
-      const bool more = (k0 + KT) < kend;
-      const R* Sc = smem + buf * 2 * LT;
-      const R* Sn = smem + (buf ^ 1) * 2 * LT;
-      if (more && !(ABL & 2)) {
-        da.advance();
-        db.advance();
-        const uint32_t img = lds0 + (uint32_t)(buf ^ 1) * 2u * LTB;
-        da.issue(img);
-        db.issue(img + LTB);
-      }
+    int cs = 0;  // stage holding tile s
+    for (int s = 0; s < ntile; ++s) {
+      const bool more = (s + 1) < ntile;
+      const int nx = (cs + 1 == NS) ? 0 : cs + 1;
+      const R* Sc = smem + cs * 2 * LT;
+      const R* Sn = smem + nx * 2 * LT;
+      if (s + D < ntile && !(ABL & 2)) issue((cs + D) % NS);
 #pragma unroll
       for (int kk = 0; kk < NKK; ++kk) {
         const int cur = kk & 1, nxt = cur ^ 1;
         if (kk + 1 < NKK) {
           frag(Sc, kk + 1, fa[nxt], fb[nxt]);
         } else if (more) {
-          if (!(ABL & 1)) __syncthreads();
+          if (!(ABL & 1)) {
+            // tile s+1 must have landed; tiles s+2 .. s+D may stay in flight (fewer at the tail)
+            if (s + D < ntile) dma_wait_barrier<(D - 1) * OPS>();
+            else dma_wait_barrier<0>();
+          }
           frag(Sn, 0, fa[nxt], fb[nxt]);
         }
 #pragma unroll
@@ -322,7 +345,7 @@ __device__ __forceinline__ void gemm_mainloop(const R* __restrict__ A, int64_t l
 #pragma unroll
           for (int ni = 0; ni < MI; ++ni) acc[mi][ni] = Real<R>::mfma(fa[cur][mi], fb[cur][ni], acc[mi][ni]);
       }
-      buf ^= 1;
+      cs = nx;
     }
   }
 }
