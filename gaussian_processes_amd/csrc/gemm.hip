@@ -91,8 +91,10 @@ int gemm_pick_tile(const GemmArgsT<R>& a) {
   };
   static const long t128_min = getenv("GPFIT_T128_MIN") ? atol(getenv("GPFIT_T128_MIN")) : 384;
   if (ntiles(128) >= t128_min) return 128;
-  if (ntiles(64) >= 256) return 64;
-  return (a.M <= 1024 && a.N <= 1024) ? 32 : 64;
+  static const long t64_min = getenv("GPFIT_T64_MIN") ? atol(getenv("GPFIT_T64_MIN")) : 256;
+  static const long t32_dim = getenv("GPFIT_T32_DIM") ? atol(getenv("GPFIT_T32_DIM")) : 1024;
+  if (ntiles(64) >= t64_min) return 64;
+  return (a.M <= t32_dim && a.N <= t32_dim) ? 32 : 64;
 }
 
 template <typename R, int T>
