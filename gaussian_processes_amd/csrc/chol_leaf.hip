@@ -175,12 +175,13 @@ __global__ __launch_bounds__(LEAF_THREADS) void chol_leaf_kernel(const R* __rest
       R x[16];
 #pragma unroll
       for (int j = 0; j < 16; ++j) x[j] = S[row * LLD + c0 + j];
+      // column-oriented substitution: once x[k] is final the later entries take their updates
+      // independently of each other
 #pragma unroll
       for (int k = 0; k < 16; ++k) {
-        R acc = x[k];
+        x[k] *= rdiag[c0 + k];
 #pragma unroll
-        for (int j = 0; j < k; ++j) acc -= x[j] * S[(c0 + k) * LLD + c0 + j];
-        x[k] = acc * rdiag[c0 + k];
+        for (int j = k + 1; j < 16; ++j) x[j] -= x[k] * S[(c0 + j) * LLD + c0 + k];
       }
 #pragma unroll
       for (int j = 0; j < 16; ++j) S[row * LLD + c0 + j] = x[j];
