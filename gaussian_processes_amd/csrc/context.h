@@ -38,6 +38,9 @@ struct gpfit_ctx {
   std::vector<hipEvent_t> ev_pool;
   double prof_out[16] = {0};
   double last_enqueue_ms = 0.0;  // host time spent enqueuing the last fit_eval
+  // evaluation enqueued but not yet collected (gpfit_fit_eval with the async flag / _finish)
+  struct Pending { bool active = false; hipStream_t stream = nullptr; double A = 0, lambda0 = 0, sigma0 = 0;
+                   int n = 0, np = 0, d = 0, want_grad = 0, elem_bytes = 8; } pend;
 
   // cached state of the last upload / evaluation (used by estep / predict entry points)
   int cur_n = 0, cur_np = 0, cur_d = 0, cur_dp = 0;

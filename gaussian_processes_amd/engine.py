@@ -103,6 +103,15 @@ class GPFitEngine:
         behaviour); a failed Cholesky raises ``GpfitError``.  ``reuse_V=True`` promises that V is
         the matrix of the previous call on this engine (constant during an M-step) so that its
         factorisation is not repeated."""
+        return self.fit_eval_finish(self.fit_eval_async(theta, lower, upper, n_px_side, X, r, m, V, logA, lambda0,
+                                                        want_grad, want_vectors, reuse_V, _sync=True))
+
+    def fit_eval_async(self, theta, lower, upper, n_px_side, X, r, m, V, logA, lambda0, want_grad=True,
+                       want_vectors=True, reuse_V=False, _sync=False):
+        """Enqueue one evaluation on the current stream without waiting for it; returns a ticket
+        for :meth:`fit_eval_finish`.  One evaluation may be pending per engine: independent units
+        (cells, theta points) are overlapped by alternating between engines on different streams
+        (``multi.evaluate_units``)."""
         rows, cols = _grid(n_px_side)
         dtype = X.dtype if isinstance(X, torch.Tensor) and X.dtype == torch.float32 else torch.float64
         X, r, m, V = (self._dev(X, "X", dtype), self._dev(r, "r", dtype), self._dev(m, "m", dtype),
@@ -121,21 +130,32 @@ class GPFitEngine:
         lo = _lib.darr(theta_vec(lower)) if lower is not None else None
         up = _lib.darr(theta_vec(upper)) if upper is not None else None
         entry = self.lib.gpfit_fit_eval_f32 if dtype == torch.float32 else self.lib.gpfit_fit_eval
+        flags = (1 if want_grad else 0) | (2 if reuse_V else 0) | (0 if _sync else 4)
         rc = entry(self._ctx, self._stream(), _lib.darr(theta_vec(theta)), lo, up, rows, cols,
-                                     X.data_ptr(), X.stride(0), N, r.data_ptr(), m.data_ptr(), V.data_ptr(),
-                                     V.stride(0), float(logA), float(lambda0), (1 if want_grad else 0) | (2 if reuse_V else 0), out,
-                                     ptrs[0], ptrs[1], ptrs[2])
+                   X.data_ptr(), X.stride(0), N, r.data_ptr(), m.data_ptr(), V.data_ptr(),
+                   V.stride(0), float(logA), float(lambda0), flags, out, ptrs[0], ptrs[1], ptrs[2])
+        pending = (rc == 0) and not _sync
+        if rc < 0 and rc != -2:
+            _lib.check(rc, "gpfit_fit_eval")
+        # the ticket keeps the operand tensors alive until the evaluation has been collected
+        return {"rc": rc, "out": out, "pending": pending, "keep": (X, r, m, V), "lam_m": lam_m, "lam_var": lam_var, "f": f}
+
+    def fit_eval_finish(self, ticket):
+        """Wait for the evaluation behind ``ticket`` and return the result dict of :meth:`fit_eval`."""
+        rc, out = ticket["rc"], ticket["out"]
+        if ticket["pending"]:
+            rc = self.lib.gpfit_fit_eval_finish(self._ctx, out)
+            ticket["pending"] = False
         if rc > 0:
             raise _lib.GpfitError(f"gpfit_fit_eval: {_lib.last_error()} (info={rc})")
         _lib.check(rc, "gpfit_fit_eval")
-        res = {
+        return {
             "loss": out[0], "loglik": out[1], "KL": out[2],
             "grad": {k: out[3 + i] for i, k in enumerate(THETA_KEYS)},
             "logdet_K": out[9], "logdet_V": out[10], "tr_KinvV": out[11], "mKinvm": out[12],
             "d": int(out[13]) if rc == 0 else 0, "in_bounds": rc == 0,
-            "lam_m": lam_m, "lam_var": lam_var, "f": f,
+            "lam_m": ticket["lam_m"], "lam_var": ticket["lam_var"], "f": ticket["f"],
         }
-        return res
 
 
 def fits_flops(N: int, d: int) -> float:

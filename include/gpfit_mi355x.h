@@ -95,8 +95,12 @@ int gpfit_acosker_diag(gpfit_ctx* ctx, void* stream, double sigma0, const double
  *   9 log|K~|, 10 log|V|, 11 tr(K~^-1 V), 12 m^T K~^-1 m, 13 masked pixel count,
  *   14 info(K~), 15 info(V).
  * want_grad: bit 0 = compute the gradients; bit 1 = V is unchanged since the previous call on
- * this context (constant during an M-step): reuse its Cholesky factor and log-det.
- * lam_m/lam_var/f (device, [N]) may be NULL.  Synchronises `stream` before returning.
+ * this context (constant during an M-step): reuse its Cholesky factor and log-det; bit 2 =
+ * asynchronous: only enqueue on `stream` and return (out_host is not written); the caller collects
+ * the result with gpfit_fit_eval_finish.  Independent units (other cells, other theta points) can
+ * then be kept in flight on several contexts / streams, so that one unit's latency-bound
+ * factorisation overlaps another's GEMMs (multi.py).
+ * lam_m/lam_var/f (device, [N]) may be NULL.  Synchronises `stream` before returning unless bit 2.
  * Returns 0; -2 when theta is outside [lower, upper] (out_host[0] = +inf and gradients
  * +inf, exactly what the reference closure hands to L-BFGS); > 0 LAPACK info. */
 int gpfit_fit_eval(gpfit_ctx* ctx, void* stream, const double* theta, const double* lower,
@@ -104,6 +108,11 @@ int gpfit_fit_eval(gpfit_ctx* ctx, void* stream, const double* theta, const doub
                    const double* r, const double* m, const double* V, int64_t ldv, double logA,
                    double lambda0, int want_grad, double* out_host, double* lam_m, double* lam_var,
                    double* f);
+
+/* Collect the evaluation enqueued on `ctx` by gpfit_fit_eval / gpfit_fit_eval_f32 with bit 2 of
+ * want_grad: waits for its stream, writes out_host[16] and returns what the synchronous call
+ * would have returned (0 or the LAPACK info).  -3 if nothing is pending. */
+int gpfit_fit_eval_finish(gpfit_ctx* ctx, double* out_host);
 
 /* Cholesky factorisation A = L L^T of a symmetric positive definite n x n matrix (lower
  * triangle read) by the recursive MFMA algorithm; replaces torch.linalg.cholesky in log_det

@@ -21,6 +21,7 @@ from gaussian_processes_amd import utils as gp
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--cells", type=int, default=64)
+ap.add_argument("--depth", type=int, default=2, help="independent cells kept in flight per GPU (config3)")
 ap.add_argument("--grid-points", type=int, default=0, help="theta points to evaluate (default: 8 per rank)")
 args = ap.parse_args()
 world = int(os.environ.get("WORLD_SIZE", "1")); rank = int(os.environ.get("RANK", "0")); lrank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -104,7 +105,34 @@ table = multi.run_sharded(cells, eval_cell, dev)
 el = max_over_ranks(sync_time() - t0)
 emit(config=f"{cells} independent cells x N=4096 d=128, cyclic shard, X broadcast once", metric="cells/s",
      value=round(cells / el, 3), n_gpus=world, seconds=round(el, 3), finite=bool(torch.isfinite(table).all()))
-del inputs, eng, V
+
+# same cells, two in flight on two contexts / streams (asynchronous entry point)
+engs = [eng] + [GPFitEngine(N, d, device=lrank) for _ in range(args.depth - 1)]
+streams = [torch.cuda.Stream(device=dev) for _ in engs]
+
+
+def submit_cell(c, slot):
+    rc, mc, Vc, thc = inputs[c]
+    with torch.cuda.stream(streams[slot]):
+        return engs[slot].fit_eval_async(thc, lower, upper, grid, X, rc, mc, Vc, logA, lam0, want_vectors=False)
+
+
+def collect_cell(ticket, slot):
+    o = engs[slot].fit_eval_finish(ticket)
+    return [o["loss"]] + [o["grad"][k] for k in syn.THETA_KEYS]
+
+
+for sl in range(1, args.depth):
+    collect_cell(submit_cell(mine[0], sl), sl)
+t0 = sync_time()
+table2 = multi.run_sharded(cells, None, dev, submit_fn=submit_cell, collect_fn=collect_cell, depth=args.depth)
+el = max_over_ranks(sync_time() - t0)
+emit(config=f"{cells} independent cells x N=4096 d=128, cyclic shard, X broadcast once, {args.depth} cells in flight per GPU",
+     metric="cells/s", value=round(cells / el, 3), n_gpus=world, seconds=round(el, 3),
+     identical_to_sequential=bool(torch.equal(table, table2)))
+for e in engs[1:]:
+    e.close()
+del inputs, eng, engs, V
 torch.cuda.empty_cache()
 
 # ---------------------------------------------------------------- config4: theta grid x N=8192 (fp32 and fp64)

@@ -61,3 +61,26 @@ def test_two_rank_gloo_shard_and_gather(tmp_path):
     ref = np.array([eval_cell(X, u) for u in range(CELLS)])
     assert np.allclose(t0, ref, rtol=1e-12, atol=0)
     assert np.all(np.isfinite(t0)) and len(np.unique(t0[:, 0])) == CELLS
+
+
+def test_pipelined_driver_keeps_order_and_depth():
+    """evaluate_units_pipelined: results land in unit order, at most `depth` tickets are open, the
+    slot alternates -- host logic only (the GPU version is tests/test_gpu_parity.py)."""
+    open_tickets, max_open, slots = set(), [0], []
+
+    def submit(u, slot):
+        open_tickets.add(u)
+        max_open[0] = max(max_open[0], len(open_tickets))
+        slots.append(slot)
+        return u
+
+    def collect(t, slot):
+        open_tickets.remove(t)
+        return [float(t)] + [float(t) * 10 + k for k in range(6)]
+
+    units = [3, 5, 8, 13, 21]
+    out = multi.evaluate_units_pipelined(units, submit, collect, torch.device("cpu"), depth=2)
+    assert out[:, 0].tolist() == [3.0, 5.0, 8.0, 13.0, 21.0] and out[4, 6] == 215.0
+    assert max_open[0] == 2 and not open_tickets and slots == [0, 1, 0, 1, 0]
+    one = multi.evaluate_units_pipelined([7], submit, collect, torch.device("cpu"), depth=3)
+    assert one.shape == (1, 7) and one[0, 0] == 7.0

@@ -229,6 +229,53 @@ def test_sharded_cells_driver_on_one_gpu(dev):
     assert np.abs(table[:, 1:] - exp[:, 1:]).max() <= 1e-6 * np.abs(exp[:, 1:]).max()
 
 
+def test_pipelined_units_match_sequential(dev):
+    """Asynchronous entry point (want_grad bit 2 + gpfit_fit_eval_finish): independent cells kept
+    two in flight on two contexts / streams give bit-identical tables to the sequential driver;
+    an out-of-box theta in the middle of the queue still yields inf; a second enqueue on a busy
+    context is refused."""
+    from gaussian_processes_amd import multi
+    from gaussian_processes_amd.engine import GPFitEngine
+    from gaussian_processes_amd import _lib
+    N, d, cells = 640, 64, 5
+    grid = syn.grid_for(d)
+    Xd = T(syn.stimuli(N, d)).to(dev)
+    cases = []
+    for c in range(cells):
+        _, _, r, m, V, th1 = synthetic_case(N, d, cell=c)
+        if c == 2:
+            th1 = dict(th1); th1["eps_0x"] = 1.5          # outside [-1, 1]
+        cases.append((r.to(dev), m.to(dev), V.to(dev), th1))
+    engs = [GPFitEngine(N, d), GPFitEngine(N, d)]
+    streams = [torch.cuda.Stream() for _ in engs]
+    torch.cuda.synchronize()
+
+    def eval_cell(c):
+        r, m, V, th = cases[c]
+        o = engs[0].fit_eval(th, LOWER, UPPER, grid, Xd, r, m, V, LOGA, LAM0, want_vectors=False)
+        return [o["loss"]] + [o["grad"][k] for k in KEYS]
+
+    def submit(c, slot):
+        r, m, V, th = cases[c]
+        with torch.cuda.stream(streams[slot]):
+            return engs[slot].fit_eval_async(th, LOWER, UPPER, grid, Xd, r, m, V, LOGA, LAM0, want_vectors=False)
+
+    def collect(t, slot):
+        o = engs[slot].fit_eval_finish(t)
+        return [o["loss"]] + [o["grad"][k] for k in KEYS]
+
+    seq = multi.run_sharded(cells, eval_cell, dev)
+    pipe = multi.run_sharded(cells, None, dev, submit_fn=submit, collect_fn=collect, depth=2)
+    assert torch.equal(seq, pipe)
+    assert torch.isinf(seq[2]).all() and torch.isfinite(seq[[0, 1, 3, 4]]).all()
+    t = submit(0, 0)
+    with pytest.raises(_lib.GpfitError):
+        submit(1, 0)                                       # context 0 still has an evaluation pending
+    collect(t, 0)
+    for e in engs:
+        e.close()
+
+
 def test_reuse_of_V_factor_is_exact(dev):
     """reuse_V=True (V constant during an M-step) must give bit-identical results."""
     grid, X, r, m, V, th1 = synthetic_case(384, 64)
