@@ -648,6 +648,20 @@ int launch_add_diag(R* A, int64_t lda, int n, double v, hipStream_t s) {
   return 0;
 }
 
+// dst[i] = alpha * src[i]
+template <typename R>
+__global__ void scale_copy_kernel(R* __restrict__ dst, const R* __restrict__ src, int n, R alpha) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = alpha * src[i];
+}
+
+template <typename R>
+int launch_scale_copy(R* dst, const R* src, int n, double alpha, hipStream_t s) {
+  hipLaunchKernelGGL(scale_copy_kernel<R>, dim3((n + 255) / 256), dim3(256), 0, s, dst, src, n, (R)alpha);
+  GP_HIP(hipGetLastError());
+  return 0;
+}
+
 // dst[r][c] = a * dst[r][c] + b * src[r][c] over a rows x cols block (cols even, 16-byte rows)
 template <typename R>
 __global__ void axpby_block_kernel(R* __restrict__ dst, int64_t ldd, const R* __restrict__ src, int64_t lds, int rows,
@@ -853,7 +867,8 @@ int launch_fparam(const double* lam_m, const double* lam_var, const double* r, i
   template int launch_metric_contract<R>(const Theta&, const int*, int, int, int, const R*, int64_t, const R*,      \
                                          int64_t, double*, hipStream_t);                                            \
   template int launch_add_diag<R>(R*, int64_t, int, double, hipStream_t);                                           \
-  template int launch_axpby_block<R>(R*, int64_t, const R*, int64_t, int, int, double, double, hipStream_t);
+  template int launch_axpby_block<R>(R*, int64_t, const R*, int64_t, int, int, double, double, hipStream_t);          \
+  template int launch_scale_copy<R>(R*, const R*, int, double, hipStream_t);
 GP_INST(double)
 GP_INST(float)
 #undef GP_INST

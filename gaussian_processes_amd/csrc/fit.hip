@@ -397,6 +397,88 @@ static int fit_eval_impl(gpfit_ctx* c, void* stream, const double* theta, const 
   return fit_eval_finish(c, out_host);
 }
 
+// Gradient pull-back for an externally supplied adjoint: out6[p] = sum_ij W_ij dK~_p,ij +
+// sum_i gvec_i dKvec_p,i with the reference's analytic dK~_p / dKvec_p (utils.py:996-1021,
+// 1036-1044) at theta, WITHOUT materialising any dK: the same contraction to the d x d metric the
+// fused full-rank unit uses.  This is what the truncated-rank (B-projected) closure needs once its
+// n x n adjoints have been lifted to W = (B G_Kb~ + G_Kb) B^T (utils._closure_projected).
+static int grad_pullback_impl(gpfit_ctx* c, void* stream, const double* theta, int n_rows, int n_cols, const double* X,
+                              int64_t ldx, int64_t N, const double* W, int64_t ldw, const double* gvec,
+                              double* out6) {
+  using R = double;
+  auto RP = [](double* b) { return b; };
+  if (!c || !theta || !X || !W || !gvec || !out6 || N <= 0) {
+    set_error("gpfit_grad_pullback: bad argument");
+    return -3;
+  }
+  if (c->pend.active) {
+    set_error("gpfit_grad_pullback: an asynchronous evaluation is pending on this context");
+    return -3;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  const int n = (int)N, np = (int)round_up(N, TILE);
+  const int dfull = n_rows * n_cols;
+  if (np > c->np_cap || dfull > c->dfull_cap) {
+    set_error("gpfit_grad_pullback: problem larger than the context capacity");
+    return -3;
+  }
+  const int d = compute_mask(theta, n_rows, n_cols, nullptr, c->pix_host);
+  const int dp = (int)round_up(d, 32);
+  if (d <= 0 || dp > c->dp_cap) {
+    set_error("gpfit_grad_pullback: masked pixel count is zero or exceeds the context capacity");
+    return -3;
+  }
+  const Theta th = make_theta(theta);
+  const double s0sq = th.sigma0 * th.sigma0;
+  const int64_t ld = np;
+  c->lv_valid = false;  // the workspace matrices are reused
+  g_main_sk_ws = c->sk_ws[0];
+  GP_HIP(hipMemcpyAsync(c->pix, c->pix_host, (size_t)d * sizeof(int), hipMemcpyHostToDevice, s));
+  GP_TRY(launch_localker<R>(th, c->pix, d, dp, n_rows, n_cols, RP(c->Cmat), dp, nullptr, s));
+  GP_TRY(launch_gather(X, ldx, n, c->pix, d, dp, np, RP(c->Xt), ld, RP(c->Xm), dp, s));
+  GP_TRY(gemm<R>(s, 1, 1, dp, np, dp, 1.0, RP(c->Cmat), dp, RP(c->Xt), ld, 0.0, RP(c->XCt), ld, 0, 0, 0));
+  GP_TRY(launch_qvec(RP(c->Xt), RP(c->XCt), ld, dp, n, np, s0sq, RP(c->Kvec), RP(c->q), s));
+  {
+    GramArgsT<R> g{};
+    g.XCt = RP(c->XCt); g.Xt = RP(c->Xt); g.q1 = RP(c->q); g.q2 = RP(c->q); g.Kout = RP(c->Kbuf); g.Cos = RP(c->Cos);
+    g.ld1 = ld; g.ld2 = ld; g.ldk = ld; g.np1 = np; g.np2 = np; g.nv1 = n; g.nv2 = n; g.Kd = dp;
+    g.s0sq = s0sq; g.lower = 1; g.pad_identity = 1;
+    GP_TRY(launch_gram(g, s));
+  }
+  GP_TRY(launch_pack_lower(W, ldw, n, RP(c->Wbuf), ld, np, s));
+  GP_HIP(hipMemsetAsync(RP(c->bv), 0, (size_t)np * sizeof(R), s));             // no -1/2 b b^T term here
+  GP_HIP(hipMemsetAsync(RP(c->wl), 0, (size_t)np * sizeof(R), s));
+  GP_TRY(launch_scale_copy<R>(RP(c->wl), gvec, n, -1.0, s));                    // t_i = u_i / q_i + gvec_i
+  GP_TRY(launch_adjoint(RP(c->Wbuf), RP(c->Cos), ld, RP(c->bv), RP(c->q), n, np, RP(c->Abuf), c->upart, c->vpart,
+                        c->sumA_part, s));
+  const int t64 = np / 64;
+  GP_TRY(launch_adjoint_reduce(c->upart, c->vpart, c->sumA_part, t64, t64 * (t64 + 1) / 2, RP(c->q), RP(c->wl), n, np,
+                               RP(c->tvec), c->rpad, c->scal + 7, s));
+  GP_TRY(gemm<R>(s, 1, 1, np, dp, np, 1.0, RP(c->Abuf), ld, RP(c->Xm), dp, 0.0, RP(c->Ybuf), dp, 0, 0, 0));
+  GP_TRY(launch_rowscale_add(RP(c->Ybuf), dp, RP(c->Xm), dp, RP(c->tvec), np, dp, s));
+  {
+    GemmArgsT<R> g{};
+    g.A = RP(c->Xm); g.B = RP(c->Ybuf); g.C = RP(c->Mpart);
+    g.lda = dp; g.ldb = dp; g.ldc = dp;
+    g.M = dp; g.N = dp; g.K = np;
+    g.alpha = 1.0; g.beta = 0.0; g.a_kmajor = 1; g.b_kmajor = 1;
+    g.batch = 1; g.split_k = c->split_k_M; g.sC = (int64_t)dp * dp;
+    GP_TRY(launch_gemm(g, s));
+    GP_TRY(launch_reduce_slices(RP(c->Mpart), (int64_t)dp * dp, c->split_k_M, RP(c->Mmat), (int64_t)dp * dp, s));
+  }
+  GP_TRY(launch_metric_contract(th, c->pix, d, n_rows, n_cols, RP(c->Cmat), dp, RP(c->Mmat), dp, c->scal + 10, s));
+  GP_HIP(hipMemcpyAsync(c->scal_host, c->scal, 64 * sizeof(double), hipMemcpyDeviceToHost, s));
+  GP_HIP(hipStreamSynchronize(s));
+  const double* sc = c->scal_host;
+  out6[0] = th.sigma0 * (2.0 * sc[9] + 2.0 * sc[7]) - 2.0 * th.sigma0 * sc[8];  // sigma_0
+  out6[1] = sc[13];  // eps_0x
+  out6[2] = sc[14];  // eps_0y
+  out6[3] = sc[11];  // -2log2beta
+  out6[4] = sc[12];  // -log2rho2
+  out6[5] = sc[10];  // Amp
+  return 0;
+}
+
 // Wait for the evaluation enqueued on this context and assemble its 16 host scalars.
 int fit_eval_finish(gpfit_ctx* c, double* out_host) {
   if (!c || !out_host || !c->pend.active) {
@@ -473,6 +555,11 @@ int gpfit_fit_eval_f32(gpfit_ctx* c, void* stream, const double* theta, const do
 }
 
 int gpfit_fit_eval_finish(gpfit_ctx* c, double* out_host) { return fit_eval_finish(c, out_host); }
+
+int gpfit_grad_pullback(gpfit_ctx* c, void* stream, const double* theta, int n_rows, int n_cols, const double* X,
+                        int64_t ldx, int64_t N, const double* W, int64_t ldw, const double* gvec, double* out6) {
+  return grad_pullback_impl(c, stream, theta, n_rows, n_cols, X, ldx, N, W, ldw, gvec, out6);
+}
 
 int gpfit_ctx_create(int device, int64_t n_max, int64_t d_max, int64_t d_full_max, gpfit_ctx** out) {
   if (!out || n_max <= 0 || d_max <= 0) {

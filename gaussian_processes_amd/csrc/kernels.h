@@ -83,6 +83,7 @@ template <typename R>
 int launch_metric_contract(const Theta& th, const int* pix, int d, int n_rows, int n_cols, const R* C, int64_t ldc,
                            const R* M, int64_t ldm, double* grad5, hipStream_t s);
 template <typename R> int launch_add_diag(R* A, int64_t lda, int n, double v, hipStream_t s);
+template <typename R> int launch_scale_copy(R* dst, const R* src, int n, double alpha, hipStream_t s);
 // dst = a * dst + b * src over a rows x cols block (cols even)
 template <typename R>
 int launch_axpby_block(R* dst, int64_t ldd, const R* src, int64_t lds, int rows, int cols, double a, double b,

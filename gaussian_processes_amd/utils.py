@@ -645,6 +645,66 @@ def _closure_general(theta, lims, n_px_side, x, xtilde, r, B, m_b, V_b, f_params
     return -(_scalar(loglik) - _scalar(KL)), grad                                  # :2087-2089
 
 
+def _closure_projected(theta, lims, n_px_side, x, r, B, m_b, V_b, f_params):
+    """Truncated-rank M-step closure (utils.py:2030-2099 with n < n_tilde = n_t, inducing set =
+    training set) in adjoint form: the same loss as the reference's B-projected formulation, but
+    instead of materialising the six dK~_p and projecting each of them (13 + 13 GEMMs of N x N x n),
+    the n x n / N x n adjoints of the loss are formed once, lifted to
+    ``W = (B G_Kb~ + G_Kb) B^T`` and contracted with the analytic dK~_p by the fused pull-back
+    (``gpfit_grad_pullback``).  As in the reference, with n_tilde == n_t the moments use a = B
+    (utils.py:2068) while their derivatives use da_p = (dK_b,p - a dK~_b,p) K~_b^-1 (utils.py:1114);
+    collecting the coefficients of dK_b,p, dK~_b,p and dKvec_p in dKL_p - dloglik_p
+    (utils.py:1117-1120, 1266, 1331-1333) with g_m = A (r - f), g_v = -A^2 f / 2:
+      G_a   = g_m m_b^T - diag(g_v) K_b + 2 diag(g_v) B V_b
+      G_Kb  = diag(g_v) B - G_a K~_b^-1
+      G_Kb~ = 1/2 K~_b^-1 - 1/2 b b^T - 1/2 K~_b^-1 V_b K~_b^-1 + B^T G_a K~_b^-1 ,  gvec = -g_v.
+    Validated against the reference on the truncated golden fixture (1e-10) and against the
+    literal formulation (``_closure_general``) at scale."""
+    lib = _lib.load()
+    lower, upper = lims
+    th = _lib.darr(theta_vec(theta))
+    if lib.gpfit_check_limits(th, _lib.darr([_scalar(lower[k]) for k in THETA_KEYS]),
+                              _lib.darr([_scalar(upper[k]) for k in THETA_KEYS])) != 0:
+        raise ValueError(_lib.last_error())
+    C, mask = localker(theta=theta, theta_higher_lims=upper, theta_lower_lims=lower, n_px_side=n_px_side, grad=False)
+    x_m = x[:, mask].contiguous()
+    K_tilde = acosker(theta, x_m, x_m, C=C, dC=None, diag=False)
+    Kvec = acosker(theta, x_m, x2=None, C=C, dC=None, diag=True)
+    A = math.exp(_scalar(f_params['logA']))
+    lambda0 = _scalar(_lambda0_of(f_params))
+    K_b = matmul(K_tilde, B)                                                        # :2049
+    K_tilde_b = matmul(B, K_b, transA=True)                                         # :2047
+    K_tilde_b = (K_tilde_b + K_tilde_b.T) * 0.5                                     # :2048
+    Ki = spd_inverse(K_tilde_b)                                                     # :2067
+    a = B                                                                           # :2068 (n_tilde == n_t)
+    aV = matmul(a, V_b)
+    lambda_m = matmul(a, m_b)                                                       # :1090
+    lambda_var = Kvec - torch.sum(a * K_b, 1) + torch.sum(aV * a, 1)                 # :1101
+    f_mean = torch.exp(A * lambda_m + 0.5 * A * A * lambda_var + lambda0)            # :1138
+    loglik = A * torch.dot(r, lambda_m) + lambda0 * torch.sum(r) - torch.sum(f_mean)  # :1243
+    b = matmul(Ki, m_b)
+    KiV = matmul(Ki, V_b)
+    KL = (-0.5 * log_det(V_b, 'V', ignore_warning=True) + 0.5 * log_det(K_tilde_b, 'K_tilde', ignore_warning=True)
+          + 0.5 * torch.dot(m_b, b) + 0.5 * torch.trace(KiV))                        # :1326
+    g_m = A * (r - f_mean)
+    g_v = -0.5 * A * A * f_mean
+    G_a = torch.outer(g_m, m_b) - g_v[:, None] * K_b + 2.0 * g_v[:, None] * aV
+    G_aKi = matmul(G_a, Ki)
+    G_Kb = g_v[:, None] * a - G_aKi
+    G_Ktb = 0.5 * Ki - 0.5 * torch.outer(b, b) - 0.5 * matmul(KiV, Ki) + matmul(a, G_aKi, transA=True)
+    W = matmul(matmul(B, G_Ktb) + G_Kb, B, transB=True)
+    W = ((W + W.T) * 0.5).contiguous()
+    gvec = (-g_v).contiguous()
+    rows, cols = _grid(n_px_side)
+    xc = _cu(x)
+    eng = get_engine(xc.shape[0], int(mask.sum()), rows * cols)
+    out = (ctypes.c_double * 6)()
+    _lib.check(lib.gpfit_grad_pullback(eng._ctx, _stream(), th, rows, cols, xc.data_ptr(), xc.stride(0), xc.shape[0],
+                                       W.data_ptr(), W.stride(0), gvec.data_ptr(), out), "gpfit_grad_pullback")
+    grad = {k: out[i] for i, k in enumerate(THETA_KEYS)}
+    return -(_scalar(loglik) - _scalar(KL)), grad
+
+
 @torch.no_grad()
 def varGP(x, r, **kwargs):
     """Variational-GP fit (EM) with the reference's call signature and ``fit_model`` schema
@@ -878,6 +938,8 @@ def varGP(x, r, **kwargs):
                                          want_vectors=False, reuse_V=v_factored[0])
                         v_factored[0] = True  # V is constant for the rest of this M-step
                         loss, grad = res['loss'], res['grad']
+                    elif same_points and not no_fast:
+                        loss, grad = _closure_projected(theta, lims, n_px_side, x, r, B, m_b, V_b, f_params)
                     else:
                         loss, grad = _closure_general(theta, lims, n_px_side, x, xtilde, r, B, m_b, V_b, f_params,
                                                       ntilde, nt)

@@ -114,6 +114,17 @@ int gpfit_fit_eval(gpfit_ctx* ctx, void* stream, const double* theta, const doub
  * would have returned (0 or the LAPACK info).  -3 if nothing is pending. */
 int gpfit_fit_eval_finish(gpfit_ctx* ctx, double* out_host);
 
+/* Gradient pull-back for an externally supplied adjoint: out_host[6] (theta dict order) =
+ *   sum_ij W_ij dK~_p,ij + sum_i gvec_i dKvec_p,i
+ * with the reference's analytic derivatives dK~_p (acosker, utils.py:996-1021) and dKvec_p
+ * (utils.py:1036-1044) at theta, without materialising any dK (the contraction is pulled back to
+ * the d x d metric, as in gpfit_fit_eval).  X[N][ldx] un-masked stimuli, W[N][ldw] symmetric
+ * (lower triangle read), gvec[N], all device.  Serves the truncated-rank (B-projected) closure
+ * of utils.py:2047-2099, whose n x n adjoints lift to W = (B G_Kb~ + G_Kb) B^T.  Synchronises. */
+int gpfit_grad_pullback(gpfit_ctx* ctx, void* stream, const double* theta, int n_rows, int n_cols,
+                        const double* X, int64_t ldx, int64_t N, const double* W, int64_t ldw,
+                        const double* gvec, double* out_host);
+
 /* Cholesky factorisation A = L L^T of a symmetric positive definite n x n matrix (lower
  * triangle read) by the recursive MFMA algorithm; replaces torch.linalg.cholesky in log_det
  * (utils.py:1275) and, through L^-1, the LU torch.linalg.solve(., I) of the closure

@@ -49,6 +49,11 @@ with warnings.catch_warnings():
         torch.cuda.synchronize(); t0 = time.time()
         loss, grad = gp._closure_general(th1, (lower, upper), grid, X, X, r, B, m_b, V_b, fp, N, N)
         torch.cuda.synchronize(); print(f"  general closure: {time.time()-t0:.3f} s  loss {loss:.6f}", flush=True)
+    for rep in range(3):
+        torch.cuda.synchronize(); t0 = time.time()
+        loss2, grad2 = gp._closure_projected(th1, (lower, upper), grid, X, r, B, m_b, V_b, fp)
+        torch.cuda.synchronize(); print(f"  projected adjoint closure: {time.time()-t0:.4f} s  loss {loss2:.6f}  max grad dev "
+                                        f"{max(abs(grad[k]-grad2[k]) for k in grad)/max(abs(v) for v in grad.values()):.2e}", flush=True)
 
 # (3) fused E-step at the headline size
 N, d = 8192, 256

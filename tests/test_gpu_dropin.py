@@ -93,6 +93,53 @@ def test_general_closure_matches_reference(gp, name, tol):
     assert np.abs(gv - g["grad"]).max() <= 1e3 * tol * np.abs(g["grad"]).max()
 
 
+@pytest.mark.parametrize("name", ["g3_closure_trunc_N96_d16.npz", "g3_closure_full_N64.npz"])
+def test_projected_adjoint_closure_matches_reference(gp, name):
+    """the truncated-rank closure in adjoint form (no dK materialised; n x n adjoints
+    lifted to W = (B G_Kb~ + G_Kb) B^T and contracted by gpfit_grad_pullback) against the real
+    reference's B-projected closure -- on the truncated fixture (72 of 96 directions kept) and, as
+    the degenerate case B square, on a full-rank one."""
+    g = load_golden(name)
+    X, r, B, m_b, V_b = T(g["X"]), T(g["r"]), T(g["B"]), T(g["m_b"]), T(g["V_b"])
+    fp = {"logA": torch.tensor(float(g["logA"]), dtype=torch.float64),
+          "lambda0": torch.tensor(float(g["lambda0"]), dtype=torch.float64)}
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        loss, grad = gp._closure_projected(tth(g["theta"]), (LOWER, UPPER), int(g["n_px"]), X, r, B, m_b, V_b, fp)
+    assert abs(loss - float(g["loss"])) <= 1e-9 * abs(float(g["loss"]))
+    gv = np.array([grad[k] for k in KEYS])
+    assert np.abs(gv - g["grad"]).max() <= 1e-7 * np.abs(g["grad"]).max()
+
+
+def test_projected_adjoint_closure_matches_general_at_scale(gp):
+    """Same two formulations against each other at N=1536, d=256 with the reference's default
+    tolerance (a few hundred of 1536 directions kept)."""
+    N, d = 1536, 256
+    th = tth([syn.theta_eval()[k] for k in KEYS])
+    X = T(syn.stimuli(N, d))
+    r_np, m_np = syn.cell_inputs(N)
+    r, m = T(r_np), T(m_np)
+    C, mask = gp.localker(th, UPPER, LOWER, 16)
+    Kt = gp.acosker(th, X[:, mask].contiguous(), X[:, mask].contiguous(), C=C)
+    ev, evec = torch.linalg.eigh(Kt)
+    keep = ev > max(float(ev.max()) * 1e-4, 1e-4)
+    B = evec[:, keep].contiguous()
+    assert 16 < B.shape[1] < N
+    m_b = gp.matmul(B, m, transA=True)
+    V_b = gp.matmul(B, gp.matmul(0.5 * Kt, B), transA=True)
+    V_b = (V_b + V_b.T) / 2
+    fp = {"logA": torch.tensor(syn.F_PARAMS["logA"], dtype=torch.float64),
+          "lambda0": torch.tensor(syn.F_PARAMS["lambda0"], dtype=torch.float64)}
+    th2 = tth([syn.theta_eval()[k] * (1.01 if k == "Amp" else 1.0) for k in KEYS])
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        l1, g1 = gp._closure_general(th2, (LOWER, UPPER), 16, X, X, r, B, m_b, V_b, fp, N, N)
+        l2, g2 = gp._closure_projected(th2, (LOWER, UPPER), 16, X, r, B, m_b, V_b, fp)
+    assert abs(l1 - l2) <= 1e-10 * abs(l1)
+    a1, a2 = np.array([g1[k] for k in KEYS]), np.array([g2[k] for k in KEYS])
+    assert np.abs(a1 - a2).max() <= 1e-7 * np.abs(a1).max()
+
+
 def test_estep_general_and_fused(gp):
     g = load_golden("g4_estep_N64.npz")
     B, ev = T(g["B"]), T(g["eigvals"])
