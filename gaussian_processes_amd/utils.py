@@ -584,12 +584,8 @@ def nd_utility(sigma2, mu, r_masked):
 def explained_variance(rtst, f_pred, sigma=True):
     """Reliability-normalised r^2 between predicted rates and repeated test responses
     (rtst[repetitions, images]); with ``sigma`` a 1000-fold bootstrap over repetitions
-    (torch RNG -- reporting only, not part of the GP arithmetic).  The statistic is a few thousand
-    tiny reductions over [repetitions, images]: it runs on host copies (on the device each of them
-    is a kernel launch, 0.4 s in total), the results come back as device scalars."""
-    dev = _device()
-    rtst = torch.as_tensor(rtst).detach().to(device="cpu", dtype=TORCH_DTYPE)
-    f_pred = torch.as_tensor(f_pred).detach().to(device="cpu", dtype=TORCH_DTYPE)
+    (torch RNG -- reporting only, not part of the GP arithmetic)."""
+    rtst, f_pred = _cu(rtst), _cu(f_pred)
 
     def r2_of(reven, rodd):
         rel = torch.abs(torch.corrcoef(torch.stack((reven, rodd))))[0, 1]
@@ -598,13 +594,13 @@ def explained_variance(rtst, f_pred, sigma=True):
         return 0.5 * (acc_o + acc_e) / rel
 
     if not sigma:
-        return r2_of(torch.mean(rtst[0::2, :], 0), torch.mean(rtst[1::2, :], 0)).to(dev), None
+        return r2_of(torch.mean(rtst[0::2, :], 0), torch.mean(rtst[1::2, :], 0)), None
     nboot, n = 1000, rtst.shape[0]
-    vals = torch.zeros(nboot, dtype=TORCH_DTYPE)
+    vals = torch.zeros(nboot, dtype=TORCH_DTYPE, device=rtst.device)
     for i in range(nboot):
-        perm = torch.randperm(n)
+        perm = torch.randperm(n, device=rtst.device)
         vals[i] = r2_of(torch.mean(rtst[perm[0::2], :], 0), torch.mean(rtst[perm[1::2], :], 0))
-    return torch.mean(vals).to(dev), torch.std(vals).to(dev)
+    return torch.mean(vals), torch.std(vals)
 
 
 # ------------------------------------------------------------------ fit (utils.py:1568-2316)
