@@ -705,6 +705,80 @@ def _closure_projected(theta, lims, n_px_side, x, r, B, m_b, V_b, f_params):
     return -(_scalar(loglik) - _scalar(KL)), grad
 
 
+def _closure_sparse(theta, lims, n_px_side, x, xtilde, r, B, m_b, V_b, f_params):
+    """Sparse M-step closure (n_tilde < n_t: K[n_t, n_tilde] != K~, a = K_b K~_b^-1 with non-zero
+    da_p; utils.py:2030-2099, 1114-1120) in adjoint form.  Two adjoint matrices come out of the
+    same algebra as in ``_closure_projected`` (with a = K_b K~_b^-1 this time):
+      W~ = B G_Kb~ B^T  (n_tilde x n_tilde, contracts with dK~_p)  -> ``gpfit_grad_pullback`` on xtilde,
+      W_K = G_Kb B^T    (n_t x n_tilde, contracts with dK_p)       -> rectangular pull-back below:
+    with c, delta the cosine / angle matrix of (x, xtilde), A_w = W_K o (pi - delta)/pi,
+    B_m = W_K o sqrt(1 - c^2)/pi, u1 = B_m q2, u2 = B_m^T q1,
+      sum_ij W_K,ij dK_p,ij = <dC_p, x^T A_w xt + x^T diag(u1 / 2 q1) x + xt^T diag(u2 / 2 q2) xt>
+    (sigma_0: 2 s0 sum A_w + s0 sum u1/q1 + s0 sum u2/q2), from utils.py:996-1021; the dKvec term
+    adds x^T diag(gvec) x.  GEMMs on ``gpfit_dgemm``; the n_t x n_tilde element-wise passes are
+    device tensor ops.  Validated against the reference on the sparse golden fixture (1e-14)."""
+    lib = _lib.load()
+    lower, upper = lims
+    th = _lib.darr(theta_vec(theta))
+    C, mask, dC = localker(theta=theta, theta_higher_lims=upper, theta_lower_lims=lower, n_px_side=n_px_side, grad=True)
+    x_m, xt_m = x[:, mask].contiguous(), xtilde[:, mask].contiguous()
+    s0 = _scalar(theta['sigma_0'])
+    K_tilde = acosker(theta, xt_m, xt_m, C=C, dC=None, diag=False)
+    Kvec = acosker(theta, x_m, x2=None, C=C, dC=None, diag=True)
+    q1, q2 = torch.sqrt(Kvec), torch.sqrt(acosker(theta, xt_m, x2=None, C=C, dC=None, diag=True))
+    G = matmul(matmul(x_m, C), xt_m, transB=True) + s0 * s0                          # :982
+    c = torch.clip(G / (torch.outer(q1, q2) + 1e-7), -1.0, 1.0)                      # :984
+    delta = torch.acos(c)                                                           # :986
+    K = torch.outer(q1, q2) * (torch.sqrt(1 - c * c) + PI32 * c - delta * c) / PI32  # :988-990
+    A = math.exp(_scalar(f_params['logA']))
+    lambda0 = _scalar(_lambda0_of(f_params))
+    K_b = matmul(K, B)                                                              # :2049
+    K_tilde_b = matmul(B, matmul(K_tilde, B), transA=True)                          # :2047
+    K_tilde_b = (K_tilde_b + K_tilde_b.T) * 0.5                                     # :2048
+    Ki = spd_inverse(K_tilde_b)                                                     # :2067
+    a = matmul(K_b, Ki)                                                             # :2068
+    aV = matmul(a, V_b)
+    lambda_m = matmul(a, m_b)                                                       # :1090
+    lambda_var = Kvec - torch.sum(a * K_b, 1) + torch.sum(aV * a, 1)                 # :1101
+    f_mean = torch.exp(A * lambda_m + 0.5 * A * A * lambda_var + lambda0)            # :1138
+    loglik = A * torch.dot(r, lambda_m) + lambda0 * torch.sum(r) - torch.sum(f_mean)  # :1243
+    b = matmul(Ki, m_b)
+    KiV = matmul(Ki, V_b)
+    KL = (-0.5 * log_det(V_b, 'V', ignore_warning=True) + 0.5 * log_det(K_tilde_b, 'K_tilde', ignore_warning=True)
+          + 0.5 * torch.dot(m_b, b) + 0.5 * torch.trace(KiV))                        # :1326
+    g_m = A * (r - f_mean)
+    g_v = -0.5 * A * A * f_mean
+    G_a = torch.outer(g_m, m_b) - g_v[:, None] * K_b + 2.0 * g_v[:, None] * aV
+    G_aKi = matmul(G_a, Ki)
+    G_Kb = g_v[:, None] * a - G_aKi
+    G_Ktb = 0.5 * Ki - 0.5 * torch.outer(b, b) - 0.5 * matmul(KiV, Ki) + matmul(a, G_aKi, transA=True)
+    # square part: W~ against dK~_p
+    Wt = matmul(matmul(B, G_Ktb), B, transB=True)
+    Wt = ((Wt + Wt.T) * 0.5).contiguous()
+    rows, cols = _grid(n_px_side)
+    xtc = _cu(xtilde)
+    eng = get_engine(xtc.shape[0], int(mask.sum()), rows * cols)
+    zero = torch.zeros(xtc.shape[0], dtype=TORCH_DTYPE, device=xtc.device)
+    out = (ctypes.c_double * 6)()
+    _lib.check(lib.gpfit_grad_pullback(eng._ctx, _stream(), th, rows, cols, xtc.data_ptr(), xtc.stride(0), xtc.shape[0],
+                                       Wt.data_ptr(), Wt.stride(0), zero.data_ptr(), out), "gpfit_grad_pullback")
+    grad = {k: out[i] for i, k in enumerate(THETA_KEYS)}
+    # rectangular part: W_K against dK_p, and gvec against dKvec_p
+    W_K = matmul(G_Kb, B, transB=True)
+    gvec = -g_v
+    A_w = W_K * (PI32 - delta) / PI32
+    B_m = W_K * torch.sqrt(1 - c * c) / PI32
+    u1, u2 = matmul(B_m, q2), matmul(B_m, q1, transA=True)
+    M = (matmul(x_m, matmul(A_w, xt_m), transA=True) + matmul(x_m, (u1 / (2 * q1) + gvec)[:, None] * x_m, transA=True)
+         + matmul(xt_m, (u2 / (2 * q2))[:, None] * xt_m, transA=True))
+    M = (M + M.T) * 0.5
+    for k in DC_KEYS:
+        grad[k] += _scalar(torch.sum(dC[k] * M))
+    grad['sigma_0'] += 2 * s0 * _scalar(A_w.sum()) + s0 * _scalar((u1 / q1).sum()) + s0 * _scalar((u2 / q2).sum()) \
+        + 2 * s0 * _scalar(gvec.sum())
+    return -(_scalar(loglik) - _scalar(KL)), grad
+
+
 @torch.no_grad()
 def varGP(x, r, **kwargs):
     """Variational-GP fit (EM) with the reference's call signature and ``fit_model`` schema
@@ -940,6 +1014,8 @@ def varGP(x, r, **kwargs):
                         loss, grad = res['loss'], res['grad']
                     elif same_points and not no_fast:
                         loss, grad = _closure_projected(theta, lims, n_px_side, x, r, B, m_b, V_b, f_params)
+                    elif ntilde != nt and not no_fast:
+                        loss, grad = _closure_sparse(theta, lims, n_px_side, x, xtilde, r, B, m_b, V_b, f_params)
                     else:
                         loss, grad = _closure_general(theta, lims, n_px_side, x, xtilde, r, B, m_b, V_b, f_params,
                                                       ntilde, nt)

@@ -92,3 +92,33 @@ for rep in range(3):
     u = gp.nd_utility(A ** 2 * s2, A * mu + lam0, rr)
     best = int(u.argmax()); torch.cuda.synchronize(); t2 = time.time()
     print(f"active-learning scoring, {ns} candidates x N={N}: kernel rows + lambda moments {1e3*(t1-t0):.2f} ms, utility+argmax {1e3*(t2-t1):.3f} ms, best {best}", flush=True)
+
+# (5) sparse regime: nt = 4096 training points, n_tilde = 2048 inducing points, d = 256
+nt_, ntil, d = 4096, 2048, 256
+grid = syn.grid_for(d)
+X = torch.from_numpy(syn.stimuli(nt_, d)).to(dev)
+xt = X[:ntil].contiguous()
+r_np, _ = syn.cell_inputs(nt_)
+r = torch.from_numpy(r_np).to(dev)
+th0 = tth(syn.theta0())
+C, mask = gp.localker(th0, upper, lower, grid)
+Kt0 = gp.acosker(th0, xt, xt, C=C)
+gp.EIGVAL_TOL = 1e-4
+ev, evec, keep = gp._eigen_stabilise(Kt0)
+B = evec[:, keep].contiguous()
+m_b = 0.1 * torch.randn(B.shape[1], dtype=torch.float64, device=dev, generator=torch.Generator(device=dev).manual_seed(1))
+V_b = torch.diag(ev[keep]) * 0.5
+fp = {"logA": torch.tensor(syn.F_PARAMS["logA"]), "lambda0": torch.tensor(syn.F_PARAMS["lambda0"])}
+th1 = tth(syn.theta_eval())
+print(f"sparse regime nt={nt_} n_tilde={ntil}: kept {B.shape[1]}", flush=True)
+with warnings.catch_warnings():
+    warnings.simplefilter("ignore")
+    for rep in range(3):
+        torch.cuda.synchronize(); t0 = time.time()
+        loss, grad = gp._closure_general(th1, (lower, upper), grid, X, xt, r, B, m_b, V_b, fp, ntil, nt_)
+        torch.cuda.synchronize(); print(f"  general closure (sparse): {time.time()-t0:.4f} s  loss {loss:.6f}", flush=True)
+    for rep in range(3):
+        torch.cuda.synchronize(); t0 = time.time()
+        loss2, grad2 = gp._closure_sparse(th1, (lower, upper), grid, X, xt, r, B, m_b, V_b, fp)
+        torch.cuda.synchronize(); print(f"  sparse adjoint closure: {time.time()-t0:.4f} s  loss {loss2:.6f}  max grad dev "
+                                        f"{max(abs(grad[k]-grad2[k]) for k in grad)/max(abs(v) for v in grad.values()):.2e}", flush=True)

@@ -111,6 +111,47 @@ def test_projected_adjoint_closure_matches_reference(gp, name):
     assert np.abs(gv - g["grad"]).max() <= 1e-7 * np.abs(g["grad"]).max()
 
 
+def test_sparse_adjoint_closure(gp):
+    """n_tilde < n_t in adjoint form (square pull-back for dK~, rectangular one for
+    dK) against the real reference on the sparse golden fixture (n_t = 96, n_tilde = 40) and
+    against the literal formulation at n_t = 1536, n_tilde = 640 with truncation."""
+    g = load_golden("g3_closure_sparse_N96_nt40.npz")
+    X, r, B, m_b, V_b = T(g["X"]), T(g["r"]), T(g["B"]), T(g["m_b"]), T(g["V_b"])
+    xt = X[: int(g["ntilde"])].contiguous()
+    fp = {"logA": torch.tensor(float(g["logA"]), dtype=torch.float64),
+          "lambda0": torch.tensor(float(g["lambda0"]), dtype=torch.float64)}
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        loss, grad = gp._closure_sparse(tth(g["theta"]), (LOWER, UPPER), int(g["n_px"]), X, xt, r, B, m_b, V_b, fp)
+    assert abs(loss - float(g["loss"])) <= 1e-10 * abs(float(g["loss"]))
+    assert np.abs(np.array([grad[k] for k in KEYS]) - g["grad"]).max() <= 1e-8 * np.abs(g["grad"]).max()
+    # at scale, with truncation, against the literal B-projected formulation
+    N, nt_, d = 1536, 640, 256
+    th = tth([syn.theta0()[k] for k in KEYS])
+    X = T(syn.stimuli(N, d))
+    xt = X[:nt_].contiguous()
+    r = T(syn.cell_inputs(N)[0])
+    C, mask = gp.localker(th, UPPER, LOWER, 16)
+    Kt = gp.acosker(th, xt[:, mask].contiguous(), xt[:, mask].contiguous(), C=C)
+    ev, evec = torch.linalg.eigh(Kt)
+    keep = ev > max(float(ev.max()) * 1e-4, 1e-4)
+    B = evec[:, keep].contiguous()
+    assert 16 < B.shape[1] < nt_
+    gen = torch.Generator().manual_seed(3)
+    m_b = T(0.1 * torch.randn(B.shape[1], dtype=torch.float64, generator=gen).numpy())
+    V_b = torch.diag(ev[keep]) * 0.5
+    fp = {"logA": torch.tensor(syn.F_PARAMS["logA"], dtype=torch.float64),
+          "lambda0": torch.tensor(syn.F_PARAMS["lambda0"], dtype=torch.float64)}
+    th2 = tth([syn.theta_eval()[k] for k in KEYS])
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        l1, g1 = gp._closure_general(th2, (LOWER, UPPER), 16, X, xt, r, B, m_b, V_b, fp, nt_, N)
+        l2, g2 = gp._closure_sparse(th2, (LOWER, UPPER), 16, X, xt, r, B, m_b, V_b, fp)
+    assert abs(l1 - l2) <= 1e-10 * abs(l1)
+    a1, a2 = np.array([g1[k] for k in KEYS]), np.array([g2[k] for k in KEYS])
+    assert np.abs(a1 - a2).max() <= 1e-7 * np.abs(a1).max()
+
+
 def test_projected_adjoint_closure_matches_general_at_scale(gp):
     """Same two formulations against each other at N=1536, d=256 with the reference's default
     tolerance (a few hundred of 1536 directions kept)."""
