@@ -250,16 +250,17 @@ def g5():
 
 
 # ------------------------------------------------------------------ G6 varGP end to end
-def g6(tol, name, dup=0):
+def g6(tol, name, dup=0, ntilde=None):
     ref.EIGVAL_TOL = tol
     N, d = 128, 64
+    ntilde = ntilde or N
     X = torch.from_numpy(near_duplicate(syn.stimuli(N, d, seed=0), dup))
     r_np, _ = syn.cell_inputs(N)
     r = torch.from_numpy(r_np)
     th = syn.theta0()
-    fit_parameters = {"ntilde": N, "maxiter": 4, "nEstep": 2, "nMstep": 3, "nFparamstep": 3,
+    fit_parameters = {"ntilde": ntilde, "maxiter": 4, "nEstep": 2, "nMstep": 3, "nFparamstep": 3,
                       "kernfun": "acosker", "cellid": 0, "n_px_side": 8, "display_hyper": False}
-    args = {"fit_parameters": fit_parameters, "xtilde": X.clone(),
+    args = {"fit_parameters": fit_parameters, "xtilde": X[:ntilde].clone(),
             "hyperparams_tuple": (tth(th), lower, upper),
             "f_params": {"logA": torch.tensor(syn.F_PARAMS["logA"]), "lambda0": torch.tensor(syn.F_PARAMS["lambda0"])}}
     buf = io.StringIO()
@@ -272,8 +273,8 @@ def g6(tol, name, dup=0):
     Rt = torch.from_numpy(np.random.default_rng(5).poisson(0.7, (4, 6, 1)).astype(np.float64))
     with contextlib.redirect_stdout(buf), warnings_off():
         _, R_pred, _, _ = ref.test(Xs, Rt, X_train=X, at_iteration=None, **fit)
-    print(name, "kept", fit["B"].shape[1], "of", N)
-    save(name, tol=tol, N=N, d=d, dup=dup, X=X.numpy(), r=r_np, theta0=thvec(th),
+    print(name, "kept", fit["B"].shape[1], "of", ntilde)
+    save(name, tol=tol, N=N, d=d, dup=dup, ntilde=ntilde, X=X.numpy(), r=r_np, theta0=thvec(th),
          maxiter=4, nEstep=2, nMstep=3, nFparamstep=3,
          logmarginal=vt["loss_track"]["logmarginal"].numpy(), loglikelihood=vt["loss_track"]["loglikelihood"].numpy(),
          KL=vt["loss_track"]["KL"].numpy(),
@@ -309,6 +310,9 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "g8":
         g8()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "g6s":
+        g6(1e-4, "g6_vargp_sparse_N128_nt64.npz", ntilde=64)
+        sys.exit(0)
     g1()
     g2()
     g3()
@@ -316,4 +320,5 @@ if __name__ == "__main__":
     g5()
     g6(1e-14, "g6_vargp_full_N128.npz")
     g6(1e-4, "g6_vargp_trunc_N128.npz", dup=16)
+    g6(1e-4, "g6_vargp_sparse_N128_nt64.npz", ntilde=64)
     g8()

@@ -248,10 +248,12 @@ def _run_vargp(gp, g):
     N, d = int(g["N"]), int(g["d"])
     X = T(g["X"])
     r = T(g["r"])
-    fit_parameters = {"ntilde": N, "maxiter": int(g["maxiter"]), "nEstep": int(g["nEstep"]), "nMstep": int(g["nMstep"]),
+    ntilde = int(g["ntilde"]) if "ntilde" in g else N
+    fit_parameters = {"ntilde": ntilde, "maxiter": int(g["maxiter"]), "nEstep": int(g["nEstep"]), "nMstep": int(g["nMstep"]),
                       "nFparamstep": int(g["nFparamstep"]), "kernfun": "acosker", "cellid": 0, "n_px_side": 8,
                       "display_hyper": False}
-    args = {"fit_parameters": fit_parameters, "xtilde": X, "hyperparams_tuple": (tth(g["theta0"]), LOWER, UPPER),
+    xtilde = X if ntilde == N else X[:ntilde].clone()
+    args = {"fit_parameters": fit_parameters, "xtilde": xtilde, "hyperparams_tuple": (tth(g["theta0"]), LOWER, UPPER),
             "f_params": {"logA": torch.tensor(syn.F_PARAMS["logA"], dtype=torch.float64),
                          "lambda0": torch.tensor(syn.F_PARAMS["lambda0"], dtype=torch.float64)}}
     old = gp.EIGVAL_TOL
@@ -267,7 +269,8 @@ def _run_vargp(gp, g):
     return fit, err, R_pred
 
 
-@pytest.mark.parametrize("name,tol_track", [("g6_vargp_full_N128.npz", 1e-6), ("g6_vargp_trunc_N128.npz", 1e-5)])
+@pytest.mark.parametrize("name,tol_track", [("g6_vargp_full_N128.npz", 1e-6), ("g6_vargp_trunc_N128.npz", 1e-5),
+                                            ("g6_vargp_sparse_N128_nt64.npz", 1e-5)])
 def test_vargp_end_to_end_matches_reference(gp, name, tol_track):
     """Whole EM fit + prediction against the reference's tracked values (looser tolerance:
     the L-BFGS path amplifies rounding differences)."""
