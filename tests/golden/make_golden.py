@@ -25,6 +25,7 @@ import torch
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.dirname(HERE))
 sys.path.insert(0, "/root/reference/Spatial_GP_repo")
 sys.dont_write_bytecode = True
 
@@ -305,8 +306,28 @@ def g8():
          U_scalar=U0.numpy(), sigma2_scalar=0.37, mu_scalar=-1.1, r_short=r_short.numpy(), U_short=U_short.numpy())
 
 
+from active_loop import active_loop_step  # noqa: E402  (tests/active_loop.py: shared with the GPU test)
+
+
+def g9():
+    """Closed-loop step through the real reference: pool of 110 images, 48 in use."""
+    ref.EIGVAL_TOL = 1e-4
+    X = torch.from_numpy(syn.stimuli(110, 64, seed=4))
+    R = torch.from_numpy(np.random.default_rng(9).poisson(0.7, 110).astype(np.float64))
+    with contextlib.redirect_stdout(io.StringIO()), warnings_off():
+        o = active_loop_step(ref, X, R, 48, 3)
+    print("g9: best candidate", o["i_best"], "-> image", o["x_idx_best"], "kept", o["n_kept"], "refit", o["refit_logmarginal"])
+    save("g9_active_step.npz", X=X.numpy(), R=R.numpy(), n_start=48, maxiter=3, u2d=o["u2d"].numpy(), i_best=o["i_best"],
+         x_idx_best=o["x_idx_best"], K_tilde_new=o["K_tilde_new"].numpy(), start_logmarginal=o["start_logmarginal"].numpy(),
+         refit_logmarginal=o["refit_logmarginal"].numpy(), refit_theta=o["refit_theta"].numpy(),
+         refit_logA=o["refit_logA"], n_kept=o["n_kept"])
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "g9":
+        g9()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "g8":
         g8()
         sys.exit(0)
@@ -322,3 +343,4 @@ if __name__ == "__main__":
     g6(1e-4, "g6_vargp_trunc_N128.npz", dup=16)
     g6(1e-4, "g6_vargp_sparse_N128_nt64.npz", ntilde=64)
     g8()
+    g9()

@@ -343,3 +343,26 @@ def test_active_learning_scoring_step(gp):
     assert relerr(lam_m.cpu().numpy(), mu_o.numpy()) < 1e-8 and relerr(lam_var.cpu().numpy(), s2_o.numpy()) < 1e-7
     assert relerr(u.cpu().numpy(), u_o.numpy()) < 1e-6
     assert int(u.argmax()) == int(u_o.argmax())
+
+
+def test_active_learning_loop_step_matches_reference(gp):
+    """SURVEY 8 f-3 end to end: the statements of one closed-loop iteration of
+    one_cell_active_training.ipynb (tests/active_loop.py) -- fit, utility of all remaining images,
+    best image appended with the kernel matrices updated by their latest column, refit from
+    (m, V, init_kernel) -- run through this module and compared with the same statements run
+    through the real reference (fixture g9): same utilities, same image chosen, same refit."""
+    from active_loop import active_loop_step
+    g = load_golden("g9_active_step.npz")
+    with contextlib.redirect_stdout(io.StringIO()), warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        o = active_loop_step(gp, torch.from_numpy(g["X"]), torch.from_numpy(g["R"]), int(g["n_start"]), int(g["maxiter"]),
+                             dev=torch.device("cuda"))
+    assert relerr(o["start_logmarginal"].numpy(), g["start_logmarginal"]) < 1e-6
+    u = o["u2d"].cpu().numpy()
+    assert np.max(np.abs(u - g["u2d"]) / np.abs(g["u2d"])) < 1e-5
+    assert o["i_best"] == int(g["i_best"]) and o["x_idx_best"] == int(g["x_idx_best"])
+    assert relerr(o["K_tilde_new"].cpu().numpy(), g["K_tilde_new"]) < 1e-12
+    assert o["n_kept"] == int(g["n_kept"])
+    assert relerr(o["refit_logmarginal"].numpy(), g["refit_logmarginal"]) < 1e-5
+    assert np.abs(o["refit_theta"].numpy() - g["refit_theta"]).max() < 1e-4
+    assert abs(o["refit_logA"] - float(g["refit_logA"])) < 1e-4
