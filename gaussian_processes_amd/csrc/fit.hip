@@ -602,7 +602,15 @@ int gpfit_ctx_create(int device, int64_t n_max, int64_t d_max, int64_t d_full_ma
   GP_HIP(hipHostMalloc((void**)&c->scal_host, 64 * sizeof(double)));
   GP_HIP(hipHostMalloc((void**)&c->pix_host, (size_t)c->dfull_cap * sizeof(int)));
   GP_HIP(hipHostMalloc((void**)&c->info_host, 4 * sizeof(int)));
-  GP_HIP(hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking));
+  {
+    // the V chain is the shorter of the two factorisations: give its stream the lowest priority so
+    // that, whenever both have workgroups ready, the critical K~ chain is dispatched first
+    int least = 0, greatest = 0;
+    GP_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+    const char* e = getenv("GPFIT_AUX_PRIO");  // tuning knob: 0 = default priority
+    if (e && atoi(e) == 0) GP_HIP(hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking));
+    else GP_HIP(hipStreamCreateWithPriority(&c->aux, hipStreamNonBlocking, least));
+  }
   GP_HIP(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
   GP_HIP(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
   // the strict-upper tiles of every triangular work matrix are never written and must read as 0
