@@ -23,6 +23,7 @@ _SIGS = {
     "gpfit_localker_mask": (i32, [pd, i32, i32, vp, ctypes.POINTER(i64)]),
     "gpfit_localker": (i32, [vp, vp, pd, i32, i32, vp, i64, vp, vp]),
     "gpfit_acosker": (i32, [vp, vp, f64, vp, i64, i64, vp, i64, i64, i64, vp, i64, vp, vp, i64, vp]),
+    "gpfit_acosker_pullback": (i32, [vp, vp, f64, vp, i64, i64, vp, i64, i64, i64, vp, i64, vp, i64, vp, vp, i64, pd]),
     "gpfit_acosker_diag": (i32, [vp, vp, f64, vp, i64, i64, i64, vp, i64, vp, vp, vp]),
     "gpfit_fit_eval": (i32, [vp, vp, pd, pd, pd, i32, i32, vp, i64, i64, vp, vp, vp, i64, f64, f64, i32, pd,
                              vp, vp, vp]),

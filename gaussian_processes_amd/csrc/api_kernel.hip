@@ -119,6 +119,77 @@ int gpfit_acosker(gpfit_ctx* c, void* stream, double sigma0, const double* x1, i
   return 0;
 }
 
+int gpfit_acosker_pullback(gpfit_ctx* c, void* stream, double sigma0, const double* x1, int64_t ld1, int64_t n1,
+                           const double* x2, int64_t ld2, int64_t n2, int64_t d, const double* C, int64_t ldC,
+                           const double* W, int64_t ldw, const double* t1_extra, double* M_out, int64_t ldm,
+                           double* out_host) {
+  if (!c || !x1 || !x2 || !C || !W || !M_out || !out_host || n1 <= 0 || n2 <= 0 || d <= 0) {
+    set_error("gpfit_acosker_pullback: bad argument");
+    return -3;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  const int dp = (int)round_up(d, 32), np1 = (int)round_up(n1, TILE), np2 = (int)round_up(n2, TILE);
+  if (dp > c->dp_cap || np1 > c->np_cap || np2 > c->np_cap) {
+    set_error("gpfit_acosker_pullback: problem larger than the context capacity");
+    return -3;
+  }
+  const double s0sq = sigma0 * sigma0;
+  double* X1m = c->Xm;     // [np1][dp] row-major copies of the operands
+  double* X2m = c->XDt;    // the [dp][np] scratch matrices have the same element count
+  double* Zm = c->XDt2;
+  c->lv_valid = false;
+  // forward pieces: q1, q2, the cosine matrix
+  GP_TRY(launch_pad_copy(C, ldC, (int)d, (int)d, c->Cmat, dp, dp, dp, s));
+  GP_TRY(launch_gather<double>(x1, ld1, (int)n1, nullptr, (int)d, dp, np1, c->Xt, np1, X1m, dp, s));
+  GP_TRY(gemm_kk(s, dp, np1, dp, c->Cmat, dp, c->Xt, np1, c->XCt, np1));
+  GP_TRY(launch_qvec(c->Xt, c->XCt, np1, dp, (int)n1, np1, s0sq, c->Kvec, c->q, s));
+  GP_TRY(launch_gather<double>(x2, ld2, (int)n2, nullptr, (int)d, dp, np2, c->Xt2, np2, X2m, dp, s));
+  GP_TRY(gemm_kk(s, dp, np2, dp, c->Cmat, dp, c->Xt2, np2, c->XCt2, np2));
+  GP_TRY(launch_qvec(c->Xt2, c->XCt2, np2, dp, (int)n2, np2, s0sq, c->hvec, c->q2, s));
+  {
+    GramArgs g{};
+    g.XCt = c->XCt; g.Xt = c->Xt2; g.q1 = c->q; g.q2 = c->q2; g.Kout = c->Kbuf; g.Cos = c->Cos;
+    g.ld1 = np1; g.ld2 = np2; g.ldk = np2; g.np1 = np1; g.np2 = np2; g.nv1 = (int)n1; g.nv2 = (int)n2; g.Kd = dp;
+    g.s0sq = s0sq; g.lower = 0; g.pad_identity = 0;
+    g.ldcos = np2;
+    GP_TRY(launch_gram(g, s));
+  }
+  // adjoint pass: A_w [np1][np2], t1 = u1 / (2 q1) + extra, t2 = u2 / (2 q2), the three sums
+  double* t1 = c->tvec;
+  double* t2 = c->tvec + c->np_cap;
+  GP_TRY(launch_adjoint_rect(W, ldw, c->Cos, np2, c->q, c->q2, (int)n1, (int)n2, np1, np2, c->Abuf, np2, c->upart,
+                             c->vpart, c->rect_part, t1_extra, t1, t2, c->rpad, c->mpad, c->scal + 20, s));
+  // M = x1^T (A_w x2 + t1 o x1) + x2^T (t2 o x2)
+  {
+    GemmArgs g{};
+    g.A = c->Abuf; g.B = X2m; g.C = c->Ybuf; g.lda = np2; g.ldb = dp; g.ldc = dp;
+    g.M = np1; g.N = dp; g.K = np2; g.alpha = 1.0; g.beta = 0.0; g.a_kmajor = 0; g.b_kmajor = 1; g.batch = 1; g.split_k = 1;
+    GP_TRY(launch_gemm(g, s));
+  }
+  GP_TRY(launch_rowscale_add(c->Ybuf, dp, X1m, dp, t1, np1, dp, s));
+  GP_HIP(hipMemsetAsync(Zm, 0, (size_t)np2 * dp * sizeof(double), s));
+  GP_TRY(launch_rowscale_add(Zm, dp, X2m, dp, t2, np2, dp, s));
+  auto xty = [&](const double* Xa, const double* Yb, int np, double* out) -> int {
+    GemmArgs g{};
+    g.A = Xa; g.B = Yb; g.C = c->Mpart; g.lda = dp; g.ldb = dp; g.ldc = dp;
+    g.M = dp; g.N = dp; g.K = np; g.alpha = 1.0; g.beta = 0.0; g.a_kmajor = 1; g.b_kmajor = 1;
+    g.batch = 1; g.split_k = c->split_k_M; g.sC = (int64_t)dp * dp;
+    GP_TRY(launch_gemm(g, s));
+    return launch_reduce_slices(c->Mpart, (int64_t)dp * dp, c->split_k_M, out, (int64_t)dp * dp, s);
+  };
+  GP_TRY(xty(X1m, c->Ybuf, np1, c->Mmat));
+  GP_TRY(xty(X2m, Zm, np2, c->dCpad));
+  GP_TRY(launch_axpby_block<double>(c->Mmat, dp, c->dCpad, dp, dp, dp, 1.0, 1.0, s));
+  GP_HIP(hipMemcpy2DAsync(M_out, (size_t)ldm * sizeof(double), c->Mmat, (size_t)dp * sizeof(double),
+                          (size_t)d * sizeof(double), (size_t)d, hipMemcpyDeviceToDevice, s));
+  GP_HIP(hipMemcpyAsync(c->scal_host, c->scal, 64 * sizeof(double), hipMemcpyDeviceToHost, s));
+  GP_HIP(hipStreamSynchronize(s));
+  out_host[0] = c->scal_host[20];
+  out_host[1] = c->scal_host[21];
+  out_host[2] = c->scal_host[22];
+  return 0;
+}
+
 int gpfit_acosker_diag(gpfit_ctx* c, void* stream, double sigma0, const double* x1, int64_t ld1, int64_t n1,
                        int64_t d, const double* C, int64_t ldC, const double* dC, double* Kvec, double* dKvec) {
   if (!c || !x1 || !C || !Kvec || n1 <= 0 || d <= 0) {

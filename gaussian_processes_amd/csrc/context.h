@@ -21,6 +21,7 @@ struct gpfit_ctx {
          *yv = nullptr, *bv = nullptr, *tvec = nullptr /* 2 np */, *mpad = nullptr, *rpad = nullptr,
          *q2 = nullptr, *dq1 = nullptr, *dq2 = nullptr, *hvec = nullptr;
   double *upart = nullptr, *vpart = nullptr, *sumA_part = nullptr, *frob_part = nullptr, *trmv_part = nullptr;
+  double* rect_part = nullptr;  // (np/64)^2 per-tile sums of the rectangular adjoint
   void* sk_ws[2] = {nullptr, nullptr};  // stream-K partial-tile workspaces (main / aux stream)
   double* scal = nullptr;       // device scalars [64]
   double* scal_host = nullptr;  // pinned [64]

@@ -453,6 +453,82 @@ __global__ void adjoint_u_kernel(const double* __restrict__ upart, const double*
   tvec[i] = (R)(v - (double)wl[i]);
 }
 
+// Rectangular adjoint (x1 != x2, utils.py:996-1021 contracted with W[n1][n2]): per 64 x 64 tile
+//   Aout = W o (pi - delta)/pi ,  B_m = W o sqrt(1 - c^2)/pi ,
+//   upart[tj][i] = sum_{j in tile} B_m[i][j] q2[j] ,  vpart[ti][j] = sum_{i in tile} B_m[i][j] q1[i] ,
+//   tile_sum[ti][tj] = sum Aout.   Padding rows / columns of Aout are written as zero.
+__global__ __launch_bounds__(256) void adjoint_rect_kernel(const double* __restrict__ W, int64_t ldw,
+                                                           const double* __restrict__ Cos, int64_t ldc,
+                                                           const double* __restrict__ q1,
+                                                           const double* __restrict__ q2, int n1, int n2, int np1,
+                                                           int np2, double* __restrict__ Aout, int64_t lda,
+                                                           double* __restrict__ upart, double* __restrict__ vpart,
+                                                           double* __restrict__ tile_sum) {
+  __shared__ double colsum[4][64];
+  __shared__ double sh[17];
+  const int tj = blockIdx.x, ti = blockIdx.y;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int j = tj * 64 + tx;
+  const double qj = (j < n2) ? q2[j] : 0.0;
+  double csum = 0.0, asum = 0.0;
+  for (int rr = ty; rr < 64; rr += 4) {
+    const int i = ti * 64 + rr;
+    double aw = 0.0, bm = 0.0;
+    if (i < n1 && j < n2) {
+      const double w = W[(int64_t)i * ldw + j];
+      const double c = Cos[(int64_t)i * ldc + j];
+      aw = w * (PI32 - acos(c)) / PI32;
+      bm = w * sqrt(1.0 - c * c) / PI32;
+    }
+    Aout[(int64_t)i * lda + j] = aw;
+    asum += aw;
+    const double rs = wave_sum(bm * qj);
+    if (tx == 0) upart[(int64_t)tj * np1 + i] = rs;
+    csum += (i < n1) ? bm * q1[i] : 0.0;
+  }
+  colsum[ty][tx] = csum;
+  __syncthreads();
+  if (ty == 0) vpart[(int64_t)ti * np2 + j] = colsum[0][tx] + colsum[1][tx] + colsum[2][tx] + colsum[3][tx];
+  asum = block_sum(asum, sh);
+  if (threadIdx.x == 0) tile_sum[ti * gridDim.x + tj] = asum;
+}
+
+// u[i] = sum_t part[t][i];  tvec = u / (2 q) (+ extra);  uq = u / q   (zero on padding)
+__global__ void adjoint_rect_reduce_kernel(const double* __restrict__ part, int nt, const double* __restrict__ q,
+                                           const double* __restrict__ extra, int n, int np,
+                                           double* __restrict__ tvec, double* __restrict__ uq) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= np) return;
+  if (i >= n) {
+    tvec[i] = 0.0;
+    uq[i] = 0.0;
+    return;
+  }
+  double u = 0.0;
+  for (int t = 0; t < nt; ++t) u += part[(int64_t)t * np + i];
+  const double v = u / q[i];
+  uq[i] = v;
+  tvec[i] = 0.5 * v + (extra ? extra[i] : 0.0);
+}
+
+int launch_adjoint_rect(const double* W, int64_t ldw, const double* Cos, int64_t ldc, const double* q1,
+                        const double* q2, int n1, int n2, int np1, int np2, double* Aout, int64_t lda, double* upart,
+                        double* vpart, double* tile_sum, const double* extra1, double* t1, double* t2, double* uq1,
+                        double* uq2, double* scal3, hipStream_t s) {
+  const int g1 = np1 / 64, g2 = np2 / 64;
+  hipLaunchKernelGGL(adjoint_rect_kernel, dim3(g2, g1), dim3(256), 0, s, W, ldw, Cos, ldc, q1, q2, n1, n2, np1, np2,
+                     Aout, lda, upart, vpart, tile_sum);
+  hipLaunchKernelGGL(adjoint_rect_reduce_kernel, dim3((np1 + 255) / 256), dim3(256), 0, s, upart, g2, q1, extra1, n1,
+                     np1, t1, uq1);
+  hipLaunchKernelGGL(adjoint_rect_reduce_kernel, dim3((np2 + 255) / 256), dim3(256), 0, s, vpart, g1, q2,
+                     (const double*)nullptr, n2, np2, t2, uq2);
+  hipLaunchKernelGGL(sum_kernel<double>, dim3(1), dim3(1024), 0, s, tile_sum, g1 * g2, 1.0, scal3 + 0);
+  hipLaunchKernelGGL(sum_kernel<double>, dim3(1), dim3(1024), 0, s, uq1, n1, 1.0, scal3 + 1);
+  hipLaunchKernelGGL(sum_kernel<double>, dim3(1), dim3(1024), 0, s, uq2, n2, 1.0, scal3 + 2);
+  GP_HIP(hipGetLastError());
+  return 0;
+}
+
 template <typename R>
 int launch_adjoint(const R* W, const R* Cos, int64_t ld, const R* b, const R* q, int n, int np, R* Aout,
                    double* upart, double* vpart, double* sumA_part, hipStream_t s) {

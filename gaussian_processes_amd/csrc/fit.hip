@@ -586,6 +586,7 @@ int gpfit_ctx_create(int device, int64_t n_max, int64_t d_max, int64_t d_full_ma
   A(&c->yv, np); A(&c->bv, np); A(&c->tvec, 2 * np); A(&c->mpad, np); A(&c->rpad, np);
   const size_t t64 = np / 64;
   A(&c->upart, t64 * np); A(&c->vpart, t64 * np); A(&c->sumA_part, t64 * (t64 + 1) / 2);
+  A(&c->rect_part, t64 * t64);
   A(&c->frob_part, (np / TILE) * (np / TILE + 1) / 2); A(&c->trmv_part, (np / 512 + 1) * np);
   A(&c->scal, 64);
   for (int i = 0; i < 2 && !rc; ++i) {

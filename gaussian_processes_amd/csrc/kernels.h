@@ -89,6 +89,13 @@ template <typename R>
 int launch_axpby_block(R* dst, int64_t ldd, const R* src, int64_t lds, int rows, int cols, double a, double b,
                        hipStream_t s);
 
+// rectangular adjoint pass (W[n1][n2] against the analytic dK of acosker(x1, x2)): A_w, the two
+// u vectors as t = u/(2q) (+ extra1) and u/q, scal3 = {sum A_w, sum u1/q1, sum u2/q2}
+int launch_adjoint_rect(const double* W, int64_t ldw, const double* Cos, int64_t ldc, const double* q1,
+                        const double* q2, int n1, int n2, int np1, int np2, double* Aout, int64_t lda, double* upart,
+                        double* vpart, double* tile_sum, const double* extra1, double* t1, double* t2, double* uq1,
+                        double* uq2, double* scal3, hipStream_t s);
+
 // active-learning utility of nstar candidates (utils.py:413-525), r = list of response counts
 int launch_nd_utility(const double* sigma2, const double* mu, int64_t nstar, const double* r, int nr, double* U,
                       hipStream_t s);

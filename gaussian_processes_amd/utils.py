@@ -720,8 +720,9 @@ def _closure_sparse(theta, lims, n_px_side, x, xtilde, r, B, m_b, V_b, f_params)
     B_m = W_K o sqrt(1 - c^2)/pi, u1 = B_m q2, u2 = B_m^T q1,
       sum_ij W_K,ij dK_p,ij = <dC_p, x^T A_w xt + x^T diag(u1 / 2 q1) x + xt^T diag(u2 / 2 q2) xt>
     (sigma_0: 2 s0 sum A_w + s0 sum u1/q1 + s0 sum u2/q2), from utils.py:996-1021; the dKvec term
-    adds x^T diag(gvec) x.  GEMMs on ``gpfit_dgemm``; the n_t x n_tilde element-wise passes are
-    device tensor ops.  Validated against the reference on the sparse golden fixture (1e-14)."""
+    adds x^T diag(gvec) x.  Both pull-backs are fused entry points (``gpfit_grad_pullback``,
+    ``gpfit_acosker_pullback``); only the five d x d contractions with dC_p stay in torch.
+    Validated against the reference on the sparse golden fixture."""
     lib = _lib.load()
     lower, upper = lims
     th = _lib.darr(theta_vec(theta))
@@ -730,11 +731,7 @@ def _closure_sparse(theta, lims, n_px_side, x, xtilde, r, B, m_b, V_b, f_params)
     s0 = _scalar(theta['sigma_0'])
     K_tilde = acosker(theta, xt_m, xt_m, C=C, dC=None, diag=False)
     Kvec = acosker(theta, x_m, x2=None, C=C, dC=None, diag=True)
-    q1, q2 = torch.sqrt(Kvec), torch.sqrt(acosker(theta, xt_m, x2=None, C=C, dC=None, diag=True))
-    G = matmul(matmul(x_m, C), xt_m, transB=True) + s0 * s0                          # :982
-    c = torch.clip(G / (torch.outer(q1, q2) + 1e-7), -1.0, 1.0)                      # :984
-    delta = torch.acos(c)                                                           # :986
-    K = torch.outer(q1, q2) * (torch.sqrt(1 - c * c) + PI32 * c - delta * c) / PI32  # :988-990
+    K = acosker(theta, x_m, xt_m, C=C, dC=None, diag=False)                          # :968-990
     A = math.exp(_scalar(f_params['logA']))
     lambda0 = _scalar(_lambda0_of(f_params))
     K_b = matmul(K, B)                                                              # :2049
@@ -768,19 +765,22 @@ def _closure_sparse(theta, lims, n_px_side, x, xtilde, r, B, m_b, V_b, f_params)
     _lib.check(lib.gpfit_grad_pullback(eng._ctx, _stream(), th, rows, cols, xtc.data_ptr(), xtc.stride(0), xtc.shape[0],
                                        Wt.data_ptr(), Wt.stride(0), zero.data_ptr(), out), "gpfit_grad_pullback")
     grad = {k: out[i] for i, k in enumerate(THETA_KEYS)}
-    # rectangular part: W_K against dK_p, and gvec against dKvec_p
-    W_K = matmul(G_Kb, B, transB=True)
-    gvec = -g_v
-    A_w = W_K * (PI32 - delta) / PI32
-    B_m = W_K * torch.sqrt(1 - c * c) / PI32
-    u1, u2 = matmul(B_m, q2), matmul(B_m, q1, transA=True)
-    M = (matmul(x_m, matmul(A_w, xt_m), transA=True) + matmul(x_m, (u1 / (2 * q1) + gvec)[:, None] * x_m, transA=True)
-         + matmul(xt_m, (u2 / (2 * q2))[:, None] * xt_m, transA=True))
+    # rectangular part: W_K against dK_p, and gvec against dKvec_p (fused pull-back, nothing n_t x n_tilde x 6)
+    W_K = matmul(G_Kb, B, transB=True).contiguous()
+    gvec = (-g_v).contiguous()
+    d = int(mask.sum())
+    Cc = _cu(C)
+    M = torch.empty((d, d), dtype=TORCH_DTYPE, device=x_m.device)
+    out3 = (ctypes.c_double * 3)()
+    eng2 = get_engine(max(x_m.shape[0], xt_m.shape[0]), d, rows * cols)
+    _lib.check(lib.gpfit_acosker_pullback(eng2._ctx, _stream(), s0, x_m.data_ptr(), x_m.stride(0), x_m.shape[0],
+                                          xt_m.data_ptr(), xt_m.stride(0), xt_m.shape[0], d, Cc.data_ptr(), Cc.stride(0),
+                                          W_K.data_ptr(), W_K.stride(0), gvec.data_ptr(), M.data_ptr(), M.stride(0), out3),
+               "gpfit_acosker_pullback")
     M = (M + M.T) * 0.5
     for k in DC_KEYS:
         grad[k] += _scalar(torch.sum(dC[k] * M))
-    grad['sigma_0'] += 2 * s0 * _scalar(A_w.sum()) + s0 * _scalar((u1 / q1).sum()) + s0 * _scalar((u2 / q2).sum()) \
-        + 2 * s0 * _scalar(gvec.sum())
+    grad['sigma_0'] += s0 * (2.0 * out3[0] + out3[1] + out3[2]) + 2 * s0 * _scalar(gvec.sum())
     return -(_scalar(loglik) - _scalar(KL)), grad
 
 

@@ -80,6 +80,21 @@ int gpfit_acosker(gpfit_ctx* ctx, void* stream, double sigma0, const double* x1,
                   const double* x2, int64_t ld2, int64_t n2, int64_t d, const double* C, int64_t ldC,
                   const double* dC, double* K, int64_t ldk, double* dK);
 
+/* Rectangular pull-back for acosker(x1, x2), x1 != x2 (the K[n_t][n_tilde] of the sparse regime):
+ * for an adjoint W[n1][n2] of K, the contraction sum_ij W_ij dK_p,ij with the reference's analytic
+ * derivatives (utils.py:996-1021) reduces to <dC_p, sym(M)> for the five metric parameters and to
+ * sigma_0 (2 out[0] + out[1] + out[2]) for sigma_0, with
+ *   A_w = W o (pi - delta)/pi,  B_m = W o sqrt(1 - c^2)/pi,  u1 = B_m q2,  u2 = B_m^T q1,
+ *   M = x1^T A_w x2 + x1^T diag(u1/(2 q1) + t1_extra) x1 + x2^T diag(u2/(2 q2)) x2      (d x d),
+ *   out_host[3] = { sum A_w, sum u1/q1, sum u2/q2 }.
+ * x1[n1][ld1], x2[n2][ld2] already masked, C[d][ldC]; t1_extra[n1] may be NULL (it carries the
+ * dKvec adjoint of the closure); M_out[d][ldm] device.  Nothing n1 x n2 x 6 is materialised.
+ * Synchronises. */
+int gpfit_acosker_pullback(gpfit_ctx* ctx, void* stream, double sigma0, const double* x1, int64_t ld1,
+                           int64_t n1, const double* x2, int64_t ld2, int64_t n2, int64_t d, const double* C,
+                           int64_t ldC, const double* W, int64_t ldw, const double* t1_extra, double* M_out,
+                           int64_t ldm, double* out_host);
+
 /* acosker, diag=True (utils.py:1027-1044): Kvec[n1] = x_i C x_i + sigma_0^2 and optionally
  * dKvec[6][n1] (theta dict order). */
 int gpfit_acosker_diag(gpfit_ctx* ctx, void* stream, double sigma0, const double* x1, int64_t ld1,
