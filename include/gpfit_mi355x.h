@@ -36,7 +36,10 @@ const char* gpfit_last_error(void);
  * 1012-1017, 2047-2062, 1318-1333).  a_kmajor: 0 = A stored [M][K], 1 = A stored [K][M];
  * b_kmajor: 1 = B stored [K][N], 0 = B stored [N][K].  out_lower: compute only the 128-tiles
  * on/below the diagonal; a_tri/b_tri: 0 dense, 1 op() lower-, 2 op() upper-triangular.
- * K % 16 == 0; M, N, lda, ldb even. */
+ * K % 16 == 0; M, N, lda, ldb even.  Large launches (>= 384 output tiles of 128 x 128, K >= 1024)
+ * may use the stream-K schedule, whose partial-tile workspace is process-wide for this context-free
+ * entry point: do not run two such calls concurrently on different streams (the context-based
+ * entry points own their workspaces). */
 int gpfit_dgemm(void* stream, int a_kmajor, int b_kmajor, int M, int N, int K, double alpha,
                 const double* A, int64_t lda, const double* B, int64_t ldb, double beta, double* C,
                 int64_t ldc, int out_lower, int a_tri, int b_tri);
