@@ -13,7 +13,7 @@ os.makedirs(out_dir, exist_ok=True)
 def one(pattern):
     m = glob.glob(os.path.join(pattern))
     assert m, pattern
-    return m[0]
+    return max(m, key=os.path.getmtime)  # gpurun merges every call's files into the same directory: newest wins
 
 
 stats = list(csv.DictReader(open(one(os.path.join(trace_dir, "*", "*_kernel_stats.csv")))))
