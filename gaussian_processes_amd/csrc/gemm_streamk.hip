@@ -54,7 +54,7 @@ struct SkParams {
   R* partial;
 };
 
-constexpr int SK_SLOTS = 512;  // resident workgroups: 256 CUs x 2 (244 VGPRs, 64 KiB LDS each)
+constexpr int SK_SLOTS = 512;  // resident workgroups: 256 CUs x 2 (189 VGPRs, 64 KiB LDS each)
 
 template <typename R, bool A_KMAJOR, bool B_KMAJOR>
 __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_streamk_kernel(SkParams<R> p) {
