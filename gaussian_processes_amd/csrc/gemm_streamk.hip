@@ -3,8 +3,8 @@
 // The data-parallel launch (gemm.hip) gives every 128 x 128 output tile to one workgroup.  With
 // 2 workgroups per CU the chip runs 512 tiles at a time, so a 2080-tile SYRK takes 5 rounds
 // for 4.06 rounds of work, a 528-tile one 2 rounds for 1.03, and triangular operands (k range
-// proportional to the tile position) leave most CUs idle behind a few long tiles: measured
-// 51-58 TF/s against 66 for the dense 4096-tile case.
+// proportional to the tile position) leave most CUs idle behind a few long tiles (with the
+// register-staged main loop of the time: 51-58 TF/s against 66 for the dense 4096-tile case).
 //
 // Here the (tile, k-step) iteration space is flattened in the launch's tile-walk order and cut
 // into one equal contiguous share per resident workgroup.  A workgroup whose share starts or
