@@ -164,7 +164,8 @@ static int two_sided(const TwoSidedBufs<R>& b, int r0, int n, hipStream_t s) {
   const int k = n / TILE;
   if (n < b.min_split || k < 2) {
     GP_TRY(gemm<R>(s, 1, 1, n, n, n, 1.0, at(b.Q, r0, r0), ld, at(b.Li, r0, r0), ld, 0.0, at(b.Z, r0, r0), ld, 0, 0, 1, /*walk=*/2));
-    GP_TRY(gemm<R>(s, 1, 1, n, n, n, 0.5, at(b.Li, r0, r0), ld, at(b.Z, r0, r0), ld, 0.0, at(b.W, r0, r0), ld, 1, 2, 0, /*walk=*/1));
+    static const int wbase_walk = getenv("GPFIT_WBASE_WALK") ? atoi(getenv("GPFIT_WBASE_WALK")) : 0;
+    GP_TRY(gemm<R>(s, 1, 1, n, n, n, 0.5, at(b.Li, r0, r0), ld, at(b.Z, r0, r0), ld, 0.0, at(b.W, r0, r0), ld, 1, 2, 0, wbase_walk));
     return 0;
   }
   const int n1 = ((k + 1) / 2) * TILE, n2 = n - n1, r1 = r0 + n1;

@@ -219,7 +219,15 @@ int launch_gemm_streamk(const GemmArgsT<R>& a, hipStream_t s) {
   static const int sk_all = getenv("GPFIT_SK_ALL") ? 1 : 0;  // experiment: stream-K for every eligible launch
   if (ntiles < sk_min || (long)a.K < 1024) return 1;  // small launches: latency-, not balance-bound
   int first = 0;
-  const bool both_tri = (a.a_tri != 0 && a.b_tri != 0) || (a.out_lower && a.a_tri == 2);
+  // classes of launches that take the stream-K schedule (tuning knob, bit mask): 1 operands
+  // triangular on both sides, 2 lower output with an upper-triangular op(A), 4 tails of uniform
+  // launches.  Class 2 is off by default: since the LDS-DMA main loop its data-parallel launch
+  // (heavy rows first) is the faster one (2.86 vs 3.04 ms at N = 8192).
+  static const int sk_classes = getenv("GPFIT_SK_CLASSES") ? atoi(getenv("GPFIT_SK_CLASSES")) : 5;
+  const bool cls1 = (a.a_tri != 0 && a.b_tri != 0), cls2 = (a.out_lower && a.a_tri == 2 && a.b_tri == 0);
+  if ((cls1 && !(sk_classes & 1)) || (cls2 && !(sk_classes & 2))) return 1;
+  const bool both_tri = cls1 || cls2;
+  if (!both_tri && !(sk_classes & 4)) return 1;
   if (!both_tri && !(sk_all && ntiles < SK_SLOTS)) {
     if (a.a_tri || a.b_tri) return 1;       // one-sided triangles: the heavy-first walk already balances
     const int tail = ntiles % SK_SLOTS;
