@@ -18,6 +18,21 @@ namespace gpfit {
 static thread_local gpfit_ctx* g_prof = nullptr;
 static thread_local void* g_main_sk_ws = nullptr;  // stream-K workspace of the context being evaluated
 
+// tile-walk choices of the large launches (tuning knob GPFIT_WALKS = trsm,tmp,merge,T,Q,Rbase,H)
+static const int* walks() {
+  static int w[7] = {3, 2, 1, 1, 1, 2, 2};
+  static bool init = false;
+  if (!init) {
+    init = true;
+    if (const char* e = getenv("GPFIT_WALKS")) {
+      int v[7];
+      if (sscanf(e, "%d,%d,%d,%d,%d,%d,%d", &v[0], &v[1], &v[2], &v[3], &v[4], &v[5], &v[6]) == 7)
+        for (int i = 0; i < 7; ++i) w[i] = v[i];
+    }
+  }
+  return w;
+}
+
 static hipEvent_t prof_event(gpfit_ctx* c) {
   hipEvent_t e;
   if (!c->ev_pool.empty()) {
@@ -131,14 +146,14 @@ int potrf_rec(const CholBufsT<R>& B, int r0, int n, bool need_inv, hipStream_t s
   const int r1 = r0 + n1;
   GP_TRY(potrf_rec<R>(B, r0, n1, true, s));
   // L21 = A21 * L11^-T       (trsm as a GEMM against the explicit inverse; op(B) = Li11^T is upper)
-  GP_TRY(gemm<R>(s, 0, 0, n2, n1, n1, 1.0, at(B.A, r1, r0), ld, at(B.Li, r0, r0), ld, 0.0, at(B.L, r1, r0), ld, 0, 0, 2, /*walk=*/3, B.ws, B.sk_ws));
+  GP_TRY(gemm<R>(s, 0, 0, n2, n1, n1, 1.0, at(B.A, r1, r0), ld, at(B.Li, r0, r0), ld, 0.0, at(B.L, r1, r0), ld, 0, 0, 2, walks()[0], B.ws, B.sk_ws));
   // A22 -= L21 L21^T          (syrk, lower tiles only)
   GP_TRY(gemm<R>(s, 0, 0, n2, n2, n1, -1.0, at(B.L, r1, r0), ld, at(B.L, r1, r0), ld, 1.0, at(B.A, r1, r1), ld, 1, 0, 0, 0, B.ws, B.sk_ws));
   GP_TRY(potrf_rec<R>(B, r1, n2, need_inv, s));
   if (need_inv) {
     // Li21 = -Li22 * (L21 * Li11)
-    GP_TRY(gemm<R>(s, 0, 1, n2, n1, n1, 1.0, at(B.L, r1, r0), ld, at(B.Li, r0, r0), ld, 0.0, at(B.Tmp, r1, r0), ld, 0, 0, 1, /*walk=*/2, B.ws, B.sk_ws));
-    GP_TRY(gemm<R>(s, 0, 1, n2, n1, n2, -1.0, at(B.Li, r1, r1), ld, at(B.Tmp, r1, r0), ld, 0.0, at(B.Li, r1, r0), ld, 0, 1, 0, /*walk=*/1, B.ws, B.sk_ws));
+    GP_TRY(gemm<R>(s, 0, 1, n2, n1, n1, 1.0, at(B.L, r1, r0), ld, at(B.Li, r0, r0), ld, 0.0, at(B.Tmp, r1, r0), ld, 0, 0, 1, walks()[1], B.ws, B.sk_ws));
+    GP_TRY(gemm<R>(s, 0, 1, n2, n1, n2, -1.0, at(B.Li, r1, r1), ld, at(B.Tmp, r1, r0), ld, 0.0, at(B.Li, r1, r0), ld, 0, 1, 0, walks()[2], B.ws, B.sk_ws));
   }
   return 0;
 }
@@ -163,7 +178,7 @@ static int two_sided(const TwoSidedBufs<R>& b, int r0, int n, hipStream_t s) {
   auto at = [&](const R* base, int r, int c) { return const_cast<R*>(base) + (int64_t)r * ld + c; };
   const int k = n / TILE;
   if (n < b.min_split || k < 2) {
-    GP_TRY(gemm<R>(s, 1, 1, n, n, n, 1.0, at(b.Q, r0, r0), ld, at(b.Li, r0, r0), ld, 0.0, at(b.Z, r0, r0), ld, 0, 0, 1, /*walk=*/2));
+    GP_TRY(gemm<R>(s, 1, 1, n, n, n, 1.0, at(b.Q, r0, r0), ld, at(b.Li, r0, r0), ld, 0.0, at(b.Z, r0, r0), ld, 0, 0, 1, walks()[5]));
     static const int wbase_walk = getenv("GPFIT_WBASE_WALK") ? atoi(getenv("GPFIT_WBASE_WALK")) : 0;
     GP_TRY(gemm<R>(s, 1, 1, n, n, n, 0.5, at(b.Li, r0, r0), ld, at(b.Z, r0, r0), ld, 0.0, at(b.W, r0, r0), ld, 1, 2, 0, wbase_walk));
     return 0;
@@ -176,7 +191,7 @@ static int two_sided(const TwoSidedBufs<R>& b, int r0, int n, hipStream_t s) {
   // H = Q21 A + Z21
   GP_HIP(hipMemcpy2DAsync(H21, (size_t)ld * sizeof(R), Z21, (size_t)ld * sizeof(R), (size_t)n1 * sizeof(R), (size_t)n2,
                           hipMemcpyDeviceToDevice, s));
-  GP_TRY(gemm<R>(s, 0, 1, n2, n1, n1, 1.0, at(b.Q, r1, r0), ld, at(b.Li, r0, r0), ld, 1.0, H21, ld, 0, 0, 1, /*walk=*/2));
+  GP_TRY(gemm<R>(s, 0, 1, n2, n1, n1, 1.0, at(b.Q, r1, r0), ld, at(b.Li, r0, r0), ld, 1.0, H21, ld, 0, 0, 1, walks()[6]));
   // Z21 = H + 1/2 Q22 B ;  W21 = 1/2 C^T Z21
   GP_TRY(launch_axpby_block<R>(Z21, ld, H21, ld, n2, n1, 1.0, 1.0, s));
   static const int w21_walk = getenv("GPFIT_W21_WALK") ? atoi(getenv("GPFIT_W21_WALK")) : 0;
@@ -347,7 +362,7 @@ static int fit_eval_impl(gpfit_ctx* c, void* stream, const double* theta, const 
   // ---- join: everything that needs both factors
   GP_HIP(hipStreamWaitEvent(s, c->ev_join, 0));
   // T = L^-1 L_V (lower x lower -> lower);  tr(K~^-1 V) = ||T||_F^2
-  GP_TRY(gemm<R>(s, 0, 1, np, np, np, 1.0, RP(c->Libuf), ld, RP(c->LVbuf), ld, 0.0, RP(c->Tbuf), ld, 1, 1, 1, /*reverse=*/1));
+  GP_TRY(gemm<R>(s, 0, 1, np, np, np, 1.0, RP(c->Libuf), ld, RP(c->LVbuf), ld, 0.0, RP(c->Tbuf), ld, 1, 1, 1, walks()[3]));
   GP_TRY(launch_frob_lower(RP(c->Tbuf), ld, np, c->scal + 5, c->frob_part, s));
 
   if (want_grad) {
@@ -355,7 +370,7 @@ static int fit_eval_impl(gpfit_ctx* c, void* stream, const double* theta, const 
     //   Q = I - T T^T   lower x upper, lower tiles only          N^3/3
     //   W = 1/2 Li^T Q Li  two-sided product (two_sided above)   13/12 N^3 with one split
     //                      (direct: R = Q Li, W = 1/2 Li^T R     4/3 N^3)
-    GP_TRY(gemm<R>(s, 0, 0, np, np, np, -1.0, RP(c->Tbuf), ld, RP(c->Tbuf), ld, 0.0, RP(c->Wbuf), ld, 1, 1, 2, /*reverse=*/1));
+    GP_TRY(gemm<R>(s, 0, 0, np, np, np, -1.0, RP(c->Tbuf), ld, RP(c->Tbuf), ld, 0.0, RP(c->Wbuf), ld, 1, 1, 2, walks()[4]));
     GP_TRY(launch_add_diag(RP(c->Wbuf), ld, np, 1.0, s));
     GP_TRY(launch_symmetrize(RP(c->Wbuf), ld, np, s));
     {
