@@ -167,7 +167,7 @@ template int potrf_rec<float>(const CholBufsT<float>&, int, int, bool, hipStream
 //   Li = [A 0; B C],  H = Q21 A + 1/2 Q22 B,
 //   W11 = A^T Q11 A + B^T H + H^T B,   W21 = C^T (H + 1/2 Q22 B),   W22 = C^T Q22 C,
 // costs 3/4 n^3 plus the two half-size products (LAPACK's sygst idea), i.e. 13/12 n^3 with
-// one level.  Z and H are n x n scratch matrices with the same leading dimension.
+// one level; blocks of n >= min_split (4096) are split again: 1.02 n^3 at n = 8192.  Z and H are n x n scratch matrices with the same leading dimension.
 template <typename R>
 struct TwoSidedBufs {
   const R* Q; const R* Li; R* W; R* Z; R* H; int64_t ld; int min_split;
