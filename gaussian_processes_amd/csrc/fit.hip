@@ -112,7 +112,7 @@ double gemm_flops(const GemmArgsT<R>& g) {
 template <typename R>
 static int gemm(hipStream_t s, int a_kmajor, int b_kmajor, int M, int N, int K, double alpha, const R* A,
                 int64_t lda, const R* B, int64_t ldb, double beta, R* C, int64_t ldc, int out_lower, int a_tri,
-                int b_tri, int reverse = 0, int ws = 0, void* sk_ws = nullptr) {
+                int b_tri, int reverse = 0, int ws = 0, void* sk_ws = nullptr, bool plain = false) {
   GemmArgsT<R> g{};
   g.A = A; g.B = B; g.C = C;
   g.lda = lda; g.ldb = ldb; g.ldc = ldc;
@@ -123,7 +123,7 @@ static int gemm(hipStream_t s, int a_kmajor, int b_kmajor, int M, int N, int K, 
   g.batch = 1; g.split_k = 1; g.reverse = reverse; g.workspace = ws; g.sk_ws = sk_ws ? sk_ws : g_main_sk_ws;
   // profile kind 0: the 128-tile kernel family (the dominant kernel), 3: the small-tile instances
   ProfScope ps(s, g_prof ? gemm_flops(g) : 0.0, (g_prof && gemm_pick_tile(g) != TILE) ? 3 : 0);
-  return launch_gemm(g, s);
+  return plain ? launch_gemm_plain(g, s) : launch_gemm(g, s);  // plain: data-parallel, never stream-K
 }
 
 #define GP_TRY(expr)            \
@@ -370,7 +370,15 @@ static int fit_eval_impl(gpfit_ctx* c, void* stream, const double* theta, const 
     //   Q = I - T T^T   lower x upper, lower tiles only          N^3/3
     //   W = 1/2 Li^T Q Li  two-sided product (two_sided above)   13/12 N^3 with one split
     //                      (direct: R = Q Li, W = 1/2 Li^T R     4/3 N^3)
-    GP_TRY(gemm<R>(s, 0, 0, np, np, np, -1.0, RP(c->Tbuf), ld, RP(c->Tbuf), ld, 0.0, RP(c->Wbuf), ld, 1, 1, 2, walks()[4]));
+    {
+      // T T^T: every tile of a tile column has the same k range [0, col + 128), so the column-major
+      // heavy-first data-parallel launch keeps a column's workgroups in lock step on its B panel
+      // (2.81 vs 2.98 ms at N = 8192); below ~6000 the launch is too small to balance without stream-K
+      static const int q_plain_min = getenv("GPFIT_Q_PLAIN_MIN") ? atoi(getenv("GPFIT_Q_PLAIN_MIN")) : 6144;
+      const bool dp = np >= q_plain_min;
+      GP_TRY(gemm<R>(s, 0, 0, np, np, np, -1.0, RP(c->Tbuf), ld, RP(c->Tbuf), ld, 0.0, RP(c->Wbuf), ld, 1, 1, 2,
+                     dp ? 3 : walks()[4], 0, nullptr, dp));
+    }
     GP_TRY(launch_add_diag(RP(c->Wbuf), ld, np, 1.0, s));
     GP_TRY(launch_symmetrize(RP(c->Wbuf), ld, np, s));
     {

@@ -22,7 +22,16 @@ __global__ __launch_bounds__(GEMM_THREADS, (T == 128 || NS > 2 ? 2 : 4)) void ge
   // bit 0 = walk backwards, bit 1 = column-major (dense output only).
   const int bid = (p.reverse & 1) ? (ntiles - 1 - (int)blockIdx.x) : (int)blockIdx.x;
   int ti, tj;
-  if (p.out_lower) {
+  if (p.out_lower && (p.reverse & 2) && T == TILE) {
+    // column-major walk of the lower triangle: the tiles of a tile column share op(B)'s panel and,
+    // where the k range depends on the column only, stay at the same k (lock step in L2)
+    const int nt = tiles_n;
+    int j = (int)((2.0 * nt + 1.0 - sqrt((2.0 * nt + 1.0) * (2.0 * nt + 1.0) - 8.0 * (double)bid)) * 0.5);
+    while (j > 0 && (long)j * nt - (long)j * (j - 1) / 2 > bid) --j;
+    while ((long)(j + 1) * nt - (long)(j + 1) * j / 2 <= bid) ++j;
+    tj = j;
+    ti = j + (bid - (j * nt - j * (j - 1) / 2));
+  } else if (p.out_lower) {
     lower_tile(bid, TILE / T, ti, tj);
   } else if (p.reverse & 2) {
     const int tiles_m = ntiles / tiles_n;
