@@ -362,7 +362,13 @@ static int fit_eval_impl(gpfit_ctx* c, void* stream, const double* theta, const 
   // ---- join: everything that needs both factors
   GP_HIP(hipStreamWaitEvent(s, c->ev_join, 0));
   // T = L^-1 L_V (lower x lower -> lower);  tr(K~^-1 V) = ||T||_F^2
-  GP_TRY(gemm<R>(s, 0, 1, np, np, np, 1.0, RP(c->Libuf), ld, RP(c->LVbuf), ld, 0.0, RP(c->Tbuf), ld, 1, 1, 1, walks()[3]));
+  {
+    static const int t_plain_min = getenv("GPFIT_T_PLAIN_MIN") ? atoi(getenv("GPFIT_T_PLAIN_MIN")) : (1 << 30);
+    static const int t_plain_walk = getenv("GPFIT_T_PLAIN_WALK") ? atoi(getenv("GPFIT_T_PLAIN_WALK")) : 6;
+    const bool dp = np >= t_plain_min;
+    GP_TRY(gemm<R>(s, 0, 1, np, np, np, 1.0, RP(c->Libuf), ld, RP(c->LVbuf), ld, 0.0, RP(c->Tbuf), ld, 1, 1, 1,
+                   dp ? t_plain_walk : walks()[3], 0, nullptr, dp));
+  }
   GP_TRY(launch_frob_lower(RP(c->Tbuf), ld, np, c->scal + 5, c->frob_part, s));
 
   if (want_grad) {

@@ -68,7 +68,9 @@ __global__ __launch_bounds__(GEMM_THREADS, (T == 128 || NS > 2 ? 2 : 4)) void ge
 #pragma unroll
     for (int j = 0; j < T / 32; ++j) acc[i][j] = acc_zero<R>();
 
-  gemm_mainloop<R, A_KMAJOR, B_KMAJOR, EDGE, T, 0, NS>(A, p.lda, B, p.ldb, p.M, p.N, row0, col0, kbeg, kend, smem, acc);
+  // walk bit 2: k downwards (EDGE instances ignore it)
+  gemm_mainloop<R, A_KMAJOR, B_KMAJOR, EDGE, T, 0, NS>(A, p.lda, B, p.ldb, p.M, p.N, row0, col0, kbeg, kend, smem, acc,
+                                                       (p.reverse & 4) != 0);
 
   const R alpha = (R)p.alpha, beta = (p.split_k > 1) ? (R)0 : (R)p.beta;
   const int64_t ldc = p.ldc;

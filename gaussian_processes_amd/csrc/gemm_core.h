@@ -262,7 +262,10 @@ template <int N> __device__ __forceinline__ void dma_wait_barrier() {
 template <typename R, bool A_KMAJOR, bool B_KMAJOR, bool EDGE, int T, int ABL = 0, int NS = 2>
 __device__ __forceinline__ void gemm_mainloop(const R* __restrict__ A, int64_t lda, const R* __restrict__ B,
                                               int64_t ldb, int M, int N, int row0, int col0, int kbeg, int kend,
-                                              R* smem, typename Real<R>::acc_t (&acc)[T / 32][T / 32]) {
+                                              R* smem, typename Real<R>::acc_t (&acc)[T / 32][T / 32],
+                                              bool kdesc = false) {
+  // kdesc: walk k from kend down to kbeg, for tiles whose ranges END at a common k (a tile row of a
+  // lower x lower product): the row's workgroups then meet at the same k and share their A panel
   if constexpr (EDGE) {
     gemm_mainloop_regstage<R, A_KMAJOR, B_KMAJOR, T>(A, lda, B, ldb, M, N, row0, col0, kbeg, kend, smem, acc);
     return;
@@ -285,8 +288,12 @@ __device__ __forceinline__ void gemm_mainloop(const R* __restrict__ A, int64_t l
 
     TileDma<R, A_KMAJOR, T> da;
     TileDma<R, B_KMAJOR, T> db;
-    da.init(A, lda, row0, kbeg, wave, lane);
-    db.init(B, ldb, col0, kbeg, wave, lane);
+    da.init(A, lda, row0, kdesc ? kend - KT : kbeg, wave, lane);
+    db.init(B, ldb, col0, kdesc ? kend - KT : kbeg, wave, lane);
+    if (kdesc) {
+      da.step = -da.step;
+      db.step = -db.step;
+    }
     const uint32_t lds0 = (uint32_t)(uintptr_t)smem;  // low 32 bits of a generic LDS pointer = LDS address
     constexpr uint32_t LTB = LT * sizeof(R);
     auto issue = [&](int stage) {
