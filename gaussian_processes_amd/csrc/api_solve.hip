@@ -80,9 +80,22 @@ int gpfit_estep(gpfit_ctx* c, void* stream, const double* K, int64_t ldk, int64_
   // M = I + S K S (lower), SK = S K (dense), Kl = K (lower)
   GP_TRY(launch_estep_build(K, ldk, n, np, sv, c->Kbuf, c->Zbuf, c->Wbuf, ld, s));
   CholBufs b{c->Kbuf, c->Lbuf, c->Libuf, c->Tmp, ld, c->info, 0, c->sk_ws[0]};
-  GP_TRY(potrf_rec(b, 0, np, true, s));
   // T = L_M^-1 (S K)          lower x dense                         N^3
-  GP_TRY(gemm_full(s, 0, 1, np, np, np, 1.0, c->Libuf, ld, c->Zbuf, ld, 0.0, c->Abuf, ld, 0, 1, 0, 1, c->sk_ws[0]));
+  if (np >= 2 * TILE) {
+    // block-wise, so that the off-diagonal block of L_M^-1 is never formed (N^3/4 less):
+    //   T1 = [L^-1]11 B1 ,  T2 = [L^-1]22 (B2 - L21 T1)        with B = S K
+    const int kt = np / TILE;
+    const int n1 = ((kt + 1) / 2) * TILE, n2 = np - n1;
+    GP_TRY(potrf_rec(b, 0, np, 2, s));
+    GP_TRY(gemm_full(s, 0, 1, n1, np, n1, 1.0, c->Libuf, ld, c->Zbuf, ld, 0.0, c->Abuf, ld, 0, 1, 0, 1, c->sk_ws[0]));
+    GP_TRY(gemm_full(s, 0, 1, n2, np, n1, -1.0, c->Lbuf + (int64_t)n1 * ld, ld, c->Abuf, ld, 1.0,
+                     c->Zbuf + (int64_t)n1 * ld, ld, 0, 0, 0, 0, c->sk_ws[0]));
+    GP_TRY(gemm_full(s, 0, 1, n2, np, n2, 1.0, c->Libuf + (int64_t)n1 * ld + n1, ld, c->Zbuf + (int64_t)n1 * ld, ld, 0.0,
+                     c->Abuf + (int64_t)n1 * ld, ld, 0, 1, 0, 1, c->sk_ws[0]));
+  } else {
+    GP_TRY(potrf_rec(b, 0, np, 1, s));
+    GP_TRY(gemm_full(s, 0, 1, np, np, np, 1.0, c->Libuf, ld, c->Zbuf, ld, 0.0, c->Abuf, ld, 0, 1, 0, 1, c->sk_ws[0]));
+  }
   // V = K - T^T T             lower tiles only                      N^3
   GP_TRY(gemm_full(s, 1, 1, np, np, np, -1.0, c->Abuf, ld, c->Abuf, ld, 1.0, c->Wbuf, ld, 1, 0, 0, 0, c->sk_ws[0]));
   // m_new = V (A^2 f o m + A (r - f))                                utils.py:1431

@@ -75,9 +75,11 @@ struct CholBufsT {
 };
 using CholBufs = CholBufsT<double>;
 // Recursive blocked Cholesky of the n x n diagonal block at offset r0 (n a multiple of 128),
-// built entirely from the MFMA GEMM and the 128 x 128 leaf.  With need_inv the full inverse of
-// the factor is assembled on the way (L^-1 costs n^3/3 more; without it only n^3/12).
+// built entirely from the MFMA GEMM and the 128 x 128 leaf.  need_inv = 1: the full inverse of
+// the factor is assembled on the way (L^-1 costs n^3/3 more; 0: only n^3/12 for the sub-block
+// inverses the solves need); 2: the inverses of the two diagonal half blocks but not the
+// off-diagonal block [L^-1]21 (for callers that apply L^-1 block-wise, n^3/8 less).
 template <typename R>
-int potrf_rec(const CholBufsT<R>& B, int r0, int n, bool need_inv, hipStream_t s);
+int potrf_rec(const CholBufsT<R>& B, int r0, int n, int need_inv, hipStream_t s);
 
 }  // namespace gpfit

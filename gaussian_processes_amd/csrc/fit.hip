@@ -134,7 +134,7 @@ static int gemm(hipStream_t s, int a_kmajor, int b_kmajor, int M, int N, int K, 
 
 // ------------------------------------------------------------------ recursive Cholesky (+ inverse)
 template <typename R>
-int potrf_rec(const CholBufsT<R>& B, int r0, int n, bool need_inv, hipStream_t s) {
+int potrf_rec(const CholBufsT<R>& B, int r0, int n, int need_inv, hipStream_t s) {
   const int64_t ld = B.ld;
   auto at = [&](R* base, int r, int c) { return base + (int64_t)r * ld + c; };
   if (n == TILE) {
@@ -144,13 +144,13 @@ int potrf_rec(const CholBufsT<R>& B, int r0, int n, bool need_inv, hipStream_t s
   const int k = n / TILE;
   const int n1 = ((k + 1) / 2) * TILE, n2 = n - n1;
   const int r1 = r0 + n1;
-  GP_TRY(potrf_rec<R>(B, r0, n1, true, s));
+  GP_TRY(potrf_rec<R>(B, r0, n1, 1, s));
   // L21 = A21 * L11^-T       (trsm as a GEMM against the explicit inverse; op(B) = Li11^T is upper)
   GP_TRY(gemm<R>(s, 0, 0, n2, n1, n1, 1.0, at(B.A, r1, r0), ld, at(B.Li, r0, r0), ld, 0.0, at(B.L, r1, r0), ld, 0, 0, 2, walks()[0], B.ws, B.sk_ws));
   // A22 -= L21 L21^T          (syrk, lower tiles only)
   GP_TRY(gemm<R>(s, 0, 0, n2, n2, n1, -1.0, at(B.L, r1, r0), ld, at(B.L, r1, r0), ld, 1.0, at(B.A, r1, r1), ld, 1, 0, 0, 0, B.ws, B.sk_ws));
-  GP_TRY(potrf_rec<R>(B, r1, n2, need_inv, s));
-  if (need_inv) {
+  GP_TRY(potrf_rec<R>(B, r1, n2, need_inv ? 1 : 0, s));
+  if (need_inv == 1) {
     // Li21 = -Li22 * (L21 * Li11)
     GP_TRY(gemm<R>(s, 0, 1, n2, n1, n1, 1.0, at(B.L, r1, r0), ld, at(B.Li, r0, r0), ld, 0.0, at(B.Tmp, r1, r0), ld, 0, 0, 1, walks()[1], B.ws, B.sk_ws));
     GP_TRY(gemm<R>(s, 0, 1, n2, n1, n2, -1.0, at(B.Li, r1, r1), ld, at(B.Tmp, r1, r0), ld, 0.0, at(B.Li, r1, r0), ld, 0, 1, 0, walks()[2], B.ws, B.sk_ws));
@@ -158,8 +158,8 @@ int potrf_rec(const CholBufsT<R>& B, int r0, int n, bool need_inv, hipStream_t s
   return 0;
 }
 
-template int potrf_rec<double>(const CholBufsT<double>&, int, int, bool, hipStream_t);
-template int potrf_rec<float>(const CholBufsT<float>&, int, int, bool, hipStream_t);
+template int potrf_rec<double>(const CholBufsT<double>&, int, int, int, hipStream_t);
+template int potrf_rec<float>(const CholBufsT<float>&, int, int, int, hipStream_t);
 
 // ------------------------------------------------------------------ two-sided triangular product
 // Wout (lower) = 1/2 Li^T Q Li on the n x n diagonal block at r0, Q symmetric (stored in full),
