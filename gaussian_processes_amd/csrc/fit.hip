@@ -324,16 +324,27 @@ static int fit_eval_impl(gpfit_ctx* c, void* stream, const double* theta, const 
   const bool reuse_V = (want_grad & 2) && c->lv_valid && c->lv_n == n && c->lv_bytes == (int)sizeof(R);
   const bool async_call = (want_grad & 4) != 0;
   want_grad &= 1;
-  GP_HIP(hipEventRecord(c->ev_fork, s));
-  GP_HIP(hipStreamWaitEvent(sa, c->ev_fork, 0));
-  if (!reuse_V) {
-    c->lv_valid = false;
-    GP_TRY(launch_pack_lower(V, ldv, n, RP(c->Vbuf), ld, np, sa));
-    CholBufsT<R> bv{RP(c->Vbuf), RP(c->LVbuf), RP(c->LiVbuf), RP(c->TmpV), ld, c->info + 1, 1, c->sk_ws[1]};
-    GP_TRY(potrf_rec<R>(bv, 0, np, false, sa));
-    GP_TRY(launch_logdet(RP(c->LVbuf), ld, n, c->scal + 40, sa));
+  // The V chain starts together with potrf(K~), not at the top of the call: the two recursions have
+  // the same shape, so started together their leaf phases and their large GEMMs coincide -- a large
+  // GEMM of one chain otherwise keeps every CU occupied and the other chain's leaf (133 KiB of LDS)
+  // waits for its tail (32.5 -> 31.8 ms/fit).  GPFIT_FORK_EARLY restores the old order (tuning knob).
+  static const bool fork_late = getenv("GPFIT_FORK_EARLY") == nullptr;
+  if (!fork_late) {
+    GP_HIP(hipEventRecord(c->ev_fork, s));
+    GP_HIP(hipStreamWaitEvent(sa, c->ev_fork, 0));
   }
-  GP_HIP(hipEventRecord(c->ev_join, sa));
+  auto enqueue_v_chain = [&]() -> int {
+  if (!reuse_V) {
+      c->lv_valid = false;
+      GP_TRY(launch_pack_lower(V, ldv, n, RP(c->Vbuf), ld, np, sa));
+      CholBufsT<R> bv{RP(c->Vbuf), RP(c->LVbuf), RP(c->LiVbuf), RP(c->TmpV), ld, c->info + 1, 1, c->sk_ws[1]};
+      GP_TRY(potrf_rec<R>(bv, 0, np, false, sa));
+      GP_TRY(launch_logdet(RP(c->LVbuf), ld, n, c->scal + 40, sa));
+    }
+    GP_HIP(hipEventRecord(c->ev_join, sa));
+    return 0;
+  };
+  if (!fork_late) GP_TRY(enqueue_v_chain());
 
   // ---- main stream: metric, kernel matrix, moments, Cholesky of K~ with its inverse
   GP_TRY(launch_localker<R>(th, c->pix, d, dp, n_rows, n_cols, RP(c->Cmat), dp, nullptr, s));
@@ -350,6 +361,11 @@ static int fit_eval_impl(gpfit_ctx* c, void* stream, const double* theta, const 
   }
   GP_TRY(launch_moments(RP(c->Kvec), RP(c->q), RP(c->Cos), ld, V, ldv, m, r, n, A, lambda0, RP(c->lam_m), RP(c->lam_var), RP(c->fvec),
                         RP(c->wl), c->scal, s));
+  if (fork_late) {
+    GP_HIP(hipEventRecord(c->ev_fork, s));
+    GP_HIP(hipStreamWaitEvent(sa, c->ev_fork, 0));
+    GP_TRY(enqueue_v_chain());
+  }
   {
     CholBufsT<R> bk{RP(c->Kbuf), RP(c->Lbuf), RP(c->Libuf), RP(c->Tmp), ld, c->info + 0, 0, c->sk_ws[0]};
     GP_TRY(potrf_rec<R>(bk, 0, np, true, s));
