@@ -45,13 +45,22 @@ def evaluate_units(units: Sequence[int], eval_fn: Callable[[int], Sequence[float
 
 
 def evaluate_units_pipelined(units: Sequence[int], submit_fn: Callable[[int, int], object],
-                             collect_fn: Callable[[object, int], Sequence[float]], device, depth: int = 2) -> torch.Tensor:
+                             collect_fn: Callable[[object, int], Sequence[float]], device, depth: int = 2,
+                             lockstep: bool = False) -> torch.Tensor:
     """Keep ``depth`` independent units in flight: ``submit_fn(u, slot)`` enqueues unit u on the
     engine / stream of ``slot`` and returns a ticket, ``collect_fn(ticket, slot)`` waits for it and
     returns ``(loss, g0..g5)``.  Units are independent, so one unit's latency-bound
     Cholesky leaves and small panels overlap the next unit's large GEMMs.  Results are identical
     to :func:`evaluate_units` (each unit still runs alone on its own context)."""
     out = torch.zeros((len(units), RESULT_WIDTH), dtype=torch.float64, device=device)
+    if lockstep:
+        # groups of `depth` units submitted together and collected together: units of the same size
+        # then run in phase (their leaf phases and their large GEMMs coincide) instead of staggered
+        for g0 in range(0, len(units), depth):
+            tickets = [(i, submit_fn(units[i], i - g0), i - g0) for i in range(g0, min(g0 + depth, len(units)))]
+            for j, t, sl in tickets:
+                out[j] = torch.as_tensor(list(collect_fn(t, sl)), dtype=torch.float64, device=device)
+        return out
     inflight = []  # (index, ticket, slot)
     for i, u in enumerate(units):
         slot = i % depth
@@ -82,14 +91,14 @@ def gather_results(local: torch.Tensor, n_units: int) -> torch.Tensor:
 
 
 def run_sharded(n_units: int, eval_fn: Callable[[int], Sequence[float]], device, submit_fn=None, collect_fn=None,
-                depth: int = 2) -> torch.Tensor:
+                depth: int = 2, lockstep: bool = False) -> torch.Tensor:
     """Evaluate all units, sharded cyclically over the ranks; with ``submit_fn`` / ``collect_fn`` the
     local units are pipelined ``depth`` deep (see :func:`evaluate_units_pipelined`)."""
     world = dist.get_world_size() if dist.is_initialized() else 1
     rank = dist.get_rank() if dist.is_initialized() else 0
     mine = partition(n_units, world, rank)
     if submit_fn is not None and collect_fn is not None:
-        local = evaluate_units_pipelined(mine, submit_fn, collect_fn, device, depth)
+        local = evaluate_units_pipelined(mine, submit_fn, collect_fn, device, depth, lockstep)
     else:
         local = evaluate_units(mine, eval_fn, device)
     return gather_results(local, n_units)

@@ -21,7 +21,8 @@ from gaussian_processes_amd import utils as gp
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--cells", type=int, default=64)
-ap.add_argument("--depth", type=int, default=2, help="independent cells kept in flight per GPU (config3)")
+ap.add_argument("--lockstep", action="store_true", help="submit / collect the in-flight cells as groups (config3)")
+ap.add_argument("--depth", type=int, default=4, help="independent cells kept in flight per GPU (config3)")
 ap.add_argument("--grid-points", type=int, default=0, help="theta points to evaluate (default: 8 per rank)")
 args = ap.parse_args()
 world = int(os.environ.get("WORLD_SIZE", "1")); rank = int(os.environ.get("RANK", "0")); lrank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -125,9 +126,10 @@ def collect_cell(ticket, slot):
 for sl in range(1, args.depth):
     collect_cell(submit_cell(mine[0], sl), sl)
 t0 = sync_time()
-table2 = multi.run_sharded(cells, None, dev, submit_fn=submit_cell, collect_fn=collect_cell, depth=args.depth)
+table2 = multi.run_sharded(cells, None, dev, submit_fn=submit_cell, collect_fn=collect_cell, depth=args.depth,
+                           lockstep=args.lockstep)
 el = max_over_ranks(sync_time() - t0)
-emit(config=f"{cells} independent cells x N=4096 d=128, cyclic shard, X broadcast once, {args.depth} cells in flight per GPU",
+emit(config=f"{cells} independent cells x N=4096 d=128, cyclic shard, X broadcast once, {args.depth} cells in flight per GPU{' (lock-step groups)' if args.lockstep else ''}",
      metric="cells/s", value=round(cells / el, 3), n_gpus=world, seconds=round(el, 3),
      identical_to_sequential=bool(torch.equal(table, table2)))
 for e in engs[1:]:
