@@ -84,3 +84,7 @@ def test_pipelined_driver_keeps_order_and_depth():
     assert max_open[0] == 2 and not open_tickets and slots == [0, 1, 0, 1, 0]
     one = multi.evaluate_units_pipelined([7], submit, collect, torch.device("cpu"), depth=3)
     assert one.shape == (1, 7) and one[0, 0] == 7.0
+    # lock-step groups: submit `depth`, collect `depth`
+    slots.clear(); max_open[0] = 0
+    grp = multi.evaluate_units_pipelined(units, submit, collect, torch.device("cpu"), depth=2, lockstep=True)
+    assert torch.equal(grp, out) and max_open[0] == 2 and not open_tickets and slots == [0, 1, 0, 1, 0]

@@ -267,6 +267,8 @@ def test_pipelined_units_match_sequential(dev):
     seq = multi.run_sharded(cells, eval_cell, dev)
     pipe = multi.run_sharded(cells, None, dev, submit_fn=submit, collect_fn=collect, depth=2)
     assert torch.equal(seq, pipe)
+    grouped = multi.run_sharded(cells, None, dev, submit_fn=submit, collect_fn=collect, depth=2, lockstep=True)
+    assert torch.equal(seq, grouped)
     assert torch.isinf(seq[2]).all() and torch.isfinite(seq[[0, 1, 3, 4]]).all()
     t = submit(0, 0)
     with pytest.raises(_lib.GpfitError):
