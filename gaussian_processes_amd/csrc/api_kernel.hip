@@ -32,6 +32,7 @@ int gpfit_localker(gpfit_ctx* c, void* stream, const double* theta, int n_rows, 
     set_error("gpfit_localker: bad argument or image larger than the context capacity");
     return -3;
   }
+  GP_CTX_ENTER(c, "gpfit_localker");
   hipStream_t s = (hipStream_t)stream;
   int k = 0;
   for (int p = 0; p < n_rows * n_cols; ++p)
@@ -60,6 +61,7 @@ int gpfit_acosker(gpfit_ctx* c, void* stream, double sigma0, const double* x1, i
     set_error("gpfit_acosker: bad argument");
     return -3;
   }
+  GP_CTX_ENTER(c, "gpfit_acosker");
   hipStream_t s = (hipStream_t)stream;
   const int dp = (int)round_up(d, 32), np1 = (int)round_up(n1, TILE), np2 = (int)round_up(n2, TILE);
   if (dp > c->dp_cap || np1 > c->np_cap || np2 > c->np_cap) {
@@ -127,6 +129,7 @@ int gpfit_acosker_pullback(gpfit_ctx* c, void* stream, double sigma0, const doub
     set_error("gpfit_acosker_pullback: bad argument");
     return -3;
   }
+  GP_CTX_ENTER(c, "gpfit_acosker_pullback");
   hipStream_t s = (hipStream_t)stream;
   const int dp = (int)round_up(d, 32), np1 = (int)round_up(n1, TILE), np2 = (int)round_up(n2, TILE);
   if (dp > c->dp_cap || np1 > c->np_cap || np2 > c->np_cap) {
@@ -196,6 +199,7 @@ int gpfit_acosker_diag(gpfit_ctx* c, void* stream, double sigma0, const double* 
     set_error("gpfit_acosker_diag: bad argument");
     return -3;
   }
+  GP_CTX_ENTER(c, "gpfit_acosker_diag");
   hipStream_t s = (hipStream_t)stream;
   const int dp = (int)round_up(d, 32), np1 = (int)round_up(n1, TILE);
   if (dp > c->dp_cap || np1 > c->np_cap) {

@@ -33,6 +33,7 @@ int gpfit_potrf(gpfit_ctx* c, void* stream, const double* A, int64_t lda, int64_
     set_error("gpfit_potrf: bad argument");
     return -3;
   }
+  GP_CTX_ENTER(c, "gpfit_potrf");
   hipStream_t s = (hipStream_t)stream;
   const int np = (int)round_up(n, TILE);
   if (np > c->np_cap) {
@@ -65,6 +66,7 @@ int gpfit_estep(gpfit_ctx* c, void* stream, const double* K, int64_t ldk, int64_
     set_error("gpfit_estep: bad argument");
     return -3;
   }
+  GP_CTX_ENTER(c, "gpfit_estep");
   hipStream_t s = (hipStream_t)stream;
   const int n = (int)N, np = (int)round_up(N, TILE);
   if (np > c->np_cap) {
@@ -118,6 +120,7 @@ int gpfit_fparam_eval(gpfit_ctx* c, void* stream, const double* lam_m, const dou
     set_error("gpfit_fparam_eval: bad argument");
     return -3;
   }
+  GP_CTX_ENTER(c, "gpfit_fparam_eval");
   hipStream_t s = (hipStream_t)stream;
   GP_TRY(launch_fparam(lam_m, lam_var, r, (int)N, std::exp(logA), closed_form_lambda0, lambda0_in, f_out,
                        c->scal + 32, s));

@@ -28,6 +28,7 @@
 #include "gemm_core.h"
 #include "kernels.h"
 
+#include <atomic>
 #include <cstdlib>
 
 namespace gpfit {
@@ -317,15 +318,23 @@ __global__ __launch_bounds__(LEAF_THREADS) void chol_leaf_kernel(const R* __rest
 template <typename R>
 int launch_chol_leaf(const R* A, int64_t lda, R* L, int64_t ldl, R* Linv, int64_t ldi, int* info, int info_base,
                      hipStream_t s) {
-  static bool attr_set = false;
+  // the dynamic-LDS limit is a per-device function attribute: set it once per device (and per
+  // template instance -- this static lives in launch_chol_leaf<R>)
+  static std::atomic<bool> attr_set[64];
   constexpr size_t lds = sizeof(R) * (LEAF * LLD + LEAF);
-  if (!attr_set) {
+  int device = 0;
+  GP_HIP(hipGetDevice(&device));
+  if (device < 0 || device >= 64 || !attr_set[device].load(std::memory_order_acquire)) {
     GP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(chol_leaf_kernel<R>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_set = true;
+    if (device >= 0 && device < 64) attr_set[device].store(true, std::memory_order_release);
   }
+#ifdef GPFIT_DEV
   static int dbg = -1;  // phase-ablation switch for scripts/dev_leaf.py (timing only; wrong results)
   if (dbg < 0) dbg = getenv("GPFIT_LEAF_DBG") ? atoi(getenv("GPFIT_LEAF_DBG")) : 0;
+#else
+  constexpr int dbg = 0;
+#endif
   hipLaunchKernelGGL(chol_leaf_kernel<R>, dim3(1), dim3(LEAF_THREADS), lds, s, A, lda, L, ldl, Linv, ldi, info,
                      info_base, dbg);
   GP_HIP(hipGetLastError());

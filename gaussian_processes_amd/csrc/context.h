@@ -52,6 +52,28 @@ struct gpfit_ctx {
 
 namespace gpfit {
 
+// Every context entry point runs on the context's device whatever the caller's current device is,
+// and restores the caller's device on return.
+struct DeviceGuard {
+  int prev = -1;
+  bool switched = false;
+  explicit DeviceGuard(int device) {
+    if (hipGetDevice(&prev) == hipSuccess && prev != device) switched = (hipSetDevice(device) == hipSuccess);
+  }
+  ~DeviceGuard() {
+    if (switched) (void)hipSetDevice(prev);
+  }
+};
+// First statements of a context entry point (after its argument check): refuse to touch the
+// workspace of an evaluation that is still in flight, then pin the device.
+#define GP_CTX_ENTER(c, name)                                                                        \
+  if ((c)->pend.active) {                                                                            \
+    gpfit::set_error(name ": an asynchronous evaluation is pending on this context (collect it with " \
+                          "gpfit_fit_eval_finish first)");                                           \
+    return -3;                                                                                       \
+  }                                                                                                  \
+  gpfit::DeviceGuard _device_guard((c)->device)
+
 // profiling scope: when a context with profile=1 is evaluating, launches are bracketed by events
 void prof_begin(gpfit_ctx* c);
 void prof_end(gpfit_ctx* c);   // synchronises and fills c->prof_out

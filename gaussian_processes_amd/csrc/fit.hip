@@ -276,10 +276,7 @@ static int fit_eval_impl(gpfit_ctx* c, void* stream, const double* theta, const 
     set_error("gpfit_fit_eval: bad argument");
     return -3;
   }
-  if (c->pend.active) {
-    set_error("gpfit_fit_eval: the previous asynchronous evaluation on this context was not collected");
-    return -3;
-  }
+  GP_CTX_ENTER(c, "gpfit_fit_eval");
   const double inf = std::numeric_limits<double>::infinity();
   if (lower && upper && check_limits(theta, lower, upper) != 0) {
     // utils.py:2020-2028: out-of-box theta -> infinite loss and infinite gradients
@@ -457,10 +454,7 @@ static int grad_pullback_impl(gpfit_ctx* c, void* stream, const double* theta, i
     set_error("gpfit_grad_pullback: bad argument");
     return -3;
   }
-  if (c->pend.active) {
-    set_error("gpfit_grad_pullback: an asynchronous evaluation is pending on this context");
-    return -3;
-  }
+  GP_CTX_ENTER(c, "gpfit_grad_pullback");
   hipStream_t s = (hipStream_t)stream;
   const int n = (int)N, np = (int)round_up(N, TILE);
   const int dfull = n_rows * n_cols;
@@ -532,6 +526,7 @@ int fit_eval_finish(gpfit_ctx* c, double* out_host) {
     return -3;
   }
   c->pend.active = false;
+  DeviceGuard device_guard(c->device);
   GP_HIP(hipStreamSynchronize(c->pend.stream));
   const int n = c->pend.n, np = c->pend.np, want_grad = c->pend.want_grad;
   const double A = c->pend.A, lambda0 = c->pend.lambda0, sigma0 = c->pend.sigma0;
@@ -612,7 +607,15 @@ int gpfit_ctx_create(int device, int64_t n_max, int64_t d_max, int64_t d_full_ma
     set_error("gpfit_ctx_create: bad argument");
     return -3;
   }
-  GP_HIP(hipSetDevice(device));
+  DeviceGuard device_guard(device);  // the caller's current device is restored on return
+  {
+    int cur = -1;
+    GP_HIP(hipGetDevice(&cur));
+    if (cur != device) {
+      set_error("gpfit_ctx_create: cannot select the requested device");
+      return -3;
+    }
+  }
   gpfit_ctx* c = new gpfit_ctx();
   c->device = device;
   c->np_cap = (int)round_up(n_max, TILE);
@@ -673,7 +676,7 @@ int gpfit_ctx_create(int device, int64_t n_max, int64_t d_max, int64_t d_full_ma
 
 void gpfit_ctx_destroy(gpfit_ctx* c) {
   if (!c) return;
-  (void)hipSetDevice(c->device);
+  DeviceGuard device_guard(c->device);
   (void)hipDeviceSynchronize();
   for (void* p : c->allocs) (void)hipFree(p);
   if (c->scal_host) (void)hipHostFree(c->scal_host);

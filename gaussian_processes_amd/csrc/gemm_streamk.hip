@@ -125,10 +125,13 @@ __global__ __launch_bounds__(256) void streamk_fixup_kernel(SkParams<R> p, const
   }
 }
 
-using SkKey = std::tuple<int, int, int, int, int, int, int, int>;  // ..., K step
+// Plans hold device pointers, so the key carries the device: (device, M, N, K, lower, a_tri, b_tri, walk, element size)
+using SkKey = std::tuple<int, int, int, int, int, int, int, int, int>;
 static std::map<SkKey, SkPlan> g_plans;
 static std::mutex g_plan_mutex;
-static void* g_workspace[2] = {nullptr, nullptr};  // sized for fp64, shared by the fp32 instances
+// Fallback partial-tile workspaces of the context-free gpfit_dgemm, one per (device, stream): two
+// streams issuing large GEMMs never share partial tiles.  Sized for fp64, used by fp32 as well.
+static std::map<std::pair<int, hipStream_t>, void*> g_workspace;
 
 template <typename R>
 static int build_plan(const GemmArgsT<R>& a, int first, SkPlan& plan) {
@@ -234,11 +237,13 @@ int launch_gemm_streamk(const GemmArgsT<R>& a, hipStream_t s) {
     if (tail == 0 || tail >= 384 || ntiles < SK_SLOTS) return 1;
     first = ntiles - tail;
   }
-  const int ws = (a.workspace == 1) ? 1 : 0;
+  int device = 0;
+  GP_HIP(hipGetDevice(&device));
   SkPlan plan;
+  void* fallback_ws = nullptr;
   {
     std::lock_guard<std::mutex> lock(g_plan_mutex);
-    const SkKey key{a.M, a.N, a.K, a.out_lower, a.a_tri, a.b_tri, (a.reverse & 3) | (first ? 4 : 0), (int)sizeof(R)};
+    const SkKey key{device, a.M, a.N, a.K, a.out_lower, a.a_tri, a.b_tri, (a.reverse & 3) | (first ? 4 : 0), (int)sizeof(R)};
     auto itp = g_plans.find(key);
     if (itp == g_plans.end()) {
       SkPlan np;
@@ -247,7 +252,11 @@ int launch_gemm_streamk(const GemmArgsT<R>& a, hipStream_t s) {
       itp = g_plans.emplace(key, np).first;
     }
     plan = itp->second;
-    if (!a.sk_ws && !g_workspace[ws]) GP_HIP(hipMalloc(&g_workspace[ws], SK_WS_BYTES));
+    if (!a.sk_ws) {
+      void*& w = g_workspace[{device, s}];
+      if (!w) GP_HIP(hipMalloc(&w, SK_WS_BYTES));
+      fallback_ws = w;
+    }
   }
   if (first > 0) {  // the full rounds, data-parallel
     GemmArgsT<R> head = a;
@@ -259,7 +268,7 @@ int launch_gemm_streamk(const GemmArgsT<R>& a, hipStream_t s) {
   SkParams<R> p{};
   p.A = a.A; p.B = a.B; p.C = a.C; p.lda = a.lda; p.ldb = a.ldb; p.ldc = a.ldc; p.M = a.M; p.N = a.N;
   p.alpha = a.alpha; p.beta = a.beta; p.tiles = plan.tiles; p.ntiles = plan.ntiles; p.total = plan.total;
-  p.per_block = plan.per_block; p.partial = (R*)(a.sk_ws ? a.sk_ws : g_workspace[ws]);
+  p.per_block = plan.per_block; p.partial = (R*)(a.sk_ws ? a.sk_ws : fallback_ws);
   dim3 grid(plan.blocks), block(GEMM_THREADS);
   const int sel = (a.a_kmajor ? 2 : 0) | (a.b_kmajor ? 1 : 0);
   switch (sel) {

@@ -15,6 +15,7 @@ from __future__ import annotations
 import copy
 import ctypes
 import math
+import threading
 import warnings
 
 import torch
@@ -43,31 +44,50 @@ def _device():
 
 
 class _EnginePool:
-    """One growing workspace per device (the C context is not re-entrant: one per thread)."""
+    """One workspace per (device, host thread): the C context is not re-entrant, and the
+    reference's active-learning notebook scores candidates on a second ``threading.Thread`` while
+    the main thread fits (one_cell_active_training.ipynb:2446-2461).
+
+    A workspace only ever grows.  Growing allocates a new context and drops the pool's reference
+    to the old one, which is destroyed when its last holder lets go -- an engine a caller still
+    holds stays valid.  ``varGP`` / ``test`` size the pool once up front (``reserve``), so no
+    reallocation happens in the middle of a fit."""
 
     def __init__(self):
         self.eng = {}
+        self.lock = threading.Lock()
 
     def get(self, n, d, d_full=None):
         dev = _device()
-        key = dev.index
+        key = (dev.index, threading.get_ident())
         d_full = int(d_full or d)
-        e = self.eng.get(key)
-        if e is None or e.n_max < n or e.d_max < d or e.d_full_max < d_full:
-            n_cap = max(n, e.n_max if e else 0)
-            d_cap = max(d, e.d_max if e else 0)
-            f_cap = max(d_full, e.d_full_max if e else 0)
-            if e is not None:
-                e.close()
-            e = GPFitEngine(n_cap, d_cap, f_cap, device=key)
-            self.eng[key] = e
-        return e
+        with self.lock:
+            e = self.eng.get(key)
+            if e is None or e.n_max < n or e.d_max < d or e.d_full_max < d_full:
+                n_cap = max(n, e.n_max if e else 0)
+                d_cap = max(d, e.d_max if e else 0)
+                f_cap = max(d_full, e.d_full_max if e else 0)
+                if e is None:
+                    alive = {t.ident for t in threading.enumerate()}
+                    for k in [k for k in self.eng if k[1] not in alive]:
+                        del self.eng[k]          # contexts of threads that have ended
+                self.eng[key] = None             # release the old workspace before allocating the new one
+                del e                            # (unless a caller still holds it)
+                e = GPFitEngine(n_cap, d_cap, f_cap, device=dev.index)
+                self.eng[key] = e
+            return e
 
 
 _POOL = _EnginePool()
 
 
 def get_engine(n, d, d_full=None) -> GPFitEngine:
+    return _POOL.get(int(n), int(d), d_full)
+
+
+def reserve(n, d, d_full=None) -> GPFitEngine:
+    """Size this thread's workspace for problems up to ``n`` stimuli and ``d`` (masked) / ``d_full``
+    (image) pixels in one allocation."""
     return _POOL.get(int(n), int(d), d_full)
 
 
@@ -802,6 +822,7 @@ def varGP(x, r, **kwargs):
     x, r = _cu(x), _cu(r)
     nt, nx = x.shape
     dev = x.device
+    reserve(nt, nx, nx)
 
     fit_parameters = copy.deepcopy(kwargs['fit_parameters'])
     fit_parameters['min_tolerance'] = MIN_TOLERANCE
@@ -938,6 +959,12 @@ def varGP(x, r, **kwargs):
                                                      _scalar(f_params['logA']), m_new.data_ptr(), V_new.data_ptr(),
                                                      V_new.stride(0))
                         if rc != 0:
+                            if not bool(torch.isfinite(f_mean).all()):
+                                # the reference's LU solve lets NaNs through and reports them one step
+                                # later, in the rate-parameter closure (utils.py:1923-1924)
+                                raise ValueError(f'Nan in f_mean during f param update in Estep, closure has been '
+                                                 f'called 1 times in estep {i_estep} iteration. Try substituting '
+                                                 f'them with inf.')
                             raise torch.linalg.LinAlgError(f"Estep: {_lib.last_error()} (rc={rc})")
                         m_b = matmul(B, m_new, transA=True)
                         V_b = matmul(B, matmul(V_new, B), transA=True)
@@ -1040,24 +1067,30 @@ def varGP(x, r, **kwargs):
         err_dict['is_error'] = True
         err_dict['error'] = e
         err_dict['error_message'] = repr(e)
-        if iteration > 1:
+        if iteration <= 1:
+            # utils.py:2134-2138 / 2168-2172 re-raise here, but the `return` inside the reference's
+            # `finally` block (utils.py:2316) swallows that exception: what the caller observes is the
+            # current (not rolled-back) state with err_dict set.  Reproduced as observed.
+            print('Too few iterations iterations were done to save')
+        else:
             theta = {k: theta_track[k][iteration - 1].to(TORCH_DTYPE) for k in theta.keys()}
             f_params['logA'] = f_par_track['logA'][iteration - 1].to(TORCH_DTYPE)
             f_params[l0key] = f_par_track[l0key][iteration - 1].to(TORCH_DTYPE)
             V_b = values_track['variation_par_track']['V_b'][iteration - 1]
             m_b = values_track['variation_par_track']['m_b'][iteration - 1]
-            C, mask, K_tilde, K, Kvec, x_m = build_kernels(theta)                                           # :2196-2208
-            eigvecs, B, K_tilde_b, K_tilde_inv_b, K_b, KKtilde_inv_b = project(K_tilde, K)
-            f_mean, lambda_m, lambda_var = mean_f(f_params=f_params, calculate_moments=True, x=x_m, K_tilde=K_tilde_b,
-                                                  KKtilde_inv=KKtilde_inv_b, Kvec=Kvec, K=K_b, C=C, m=m_b, V=V_b,
-                                                  theta=theta, kernfun=kernfun)
-            loglikelihood = compute_loglikelihood(r, f_mean, lambda_m, lambda_var, f_params)[0]
-            KL_div = compute_KL_div(m_b, V_b, K_tilde_b, K_tilde_inv_b, dK_tilde=None)
-            logmarginal = loglikelihood - KL_div
-            last = fit_parameters['maxiter'] - 1
-            loss_track['loglikelihood'][last] = _scalar(loglikelihood)
-            loss_track['KL'][last] = _scalar(KL_div)
-            loss_track['logmarginal'][last] = _scalar(logmarginal)
+        # utils.py:2194-2231 (the `finally` block when is_error): kernels at the theta in force, final loss
+        C, mask, K_tilde, K, Kvec, x_m = build_kernels(theta)
+        eigvecs, B, K_tilde_b, K_tilde_inv_b, K_b, KKtilde_inv_b = project(K_tilde, K)
+        f_mean, lambda_m, lambda_var = mean_f(f_params=f_params, calculate_moments=True, x=x_m, K_tilde=K_tilde_b,
+                                              KKtilde_inv=KKtilde_inv_b, Kvec=Kvec, K=K_b, C=C, m=m_b, V=V_b,
+                                              theta=theta, kernfun=kernfun)
+        loglikelihood = compute_loglikelihood(r, f_mean, lambda_m, lambda_var, f_params)[0]
+        KL_div = compute_KL_div(m_b, V_b, K_tilde_b, K_tilde_inv_b, dK_tilde=None)
+        logmarginal = loglikelihood - KL_div
+        last = fit_parameters['maxiter'] - 1
+        loss_track['loglikelihood'][last] = _scalar(loglikelihood)
+        loss_track['KL'][last] = _scalar(KL_div)
+        loss_track['logmarginal'][last] = _scalar(logmarginal)
 
     final_kernel = {'C': C, 'mask': mask, 'K_tilde': K_tilde, 'K': K, 'Kvec': Kvec, 'eigvecs': eigvecs}
     if not is_simmetric(V_b, 'V_b'):
@@ -1106,6 +1139,7 @@ def test(X_test, R_test, xtilde, X_train=None, at_iteration=None, **kwargs):
     K_tilde, K_tilde_inv = kwargs.get('K_tilde_b'), kwargs.get('K_tilde_inv_b')
     f_params = kwargs.get('f_params')
     xtilde = _cu(xtilde)
+    reserve(xtilde.shape[0], xtilde.shape[1], xtilde.shape[1])
     A = math.exp(_scalar(f_params['logA']))
     lambda0 = _scalar(_lambda0_of(f_params))
 

@@ -36,10 +36,10 @@ const char* gpfit_last_error(void);
  * 1012-1017, 2047-2062, 1318-1333).  a_kmajor: 0 = A stored [M][K], 1 = A stored [K][M];
  * b_kmajor: 1 = B stored [K][N], 0 = B stored [N][K].  out_lower: compute only the 128-tiles
  * on/below the diagonal; a_tri/b_tri: 0 dense, 1 op() lower-, 2 op() upper-triangular.
- * K % 16 == 0; M, N, lda, ldb even.  Large launches (>= 384 output tiles of 128 x 128, K >= 1024)
- * may use the stream-K schedule, whose partial-tile workspace is process-wide for this context-free
- * entry point: do not run two such calls concurrently on different streams (the context-based
- * entry points own their workspaces). */
+ * K % 16 == 0; M, N, lda, ldb even.  Runs on the caller's current device.  Large launches (>= 384
+ * output tiles of 128 x 128, K >= 1024) may use the stream-K schedule; its partial-tile workspace is
+ * kept per (device, stream) for this context-free entry point, so calls on different streams are
+ * independent (the context-based entry points own their workspaces). */
 int gpfit_dgemm(void* stream, int a_kmajor, int b_kmajor, int M, int N, int K, double alpha,
                 const double* A, int64_t lda, const double* B, int64_t ldb, double beta, double* C,
                 int64_t ldc, int out_lower, int a_tri, int b_tri);
@@ -53,7 +53,11 @@ int gpfit_dgemm_ex(void* stream, int a_kmajor, int b_kmajor, int M, int N, int K
 /* ---- workspace context -------------------------------------------------------------
  * One context per (device, maximum problem size); owns ~13 N^2 + O(N d) doubles of HBM
  * workspace, one auxiliary HIP stream and two events.  A context is NOT re-entrant: calls
- * on the same context must be serialised by the caller (one context per Python thread).
+ * on the same context must be serialised by the caller (one context per host thread; the Python
+ * module keeps one per (device, thread)).  Every context entry point selects the context's device
+ * for the duration of the call and restores the caller's current device on return; while an
+ * asynchronous evaluation is pending (gpfit_fit_eval bit 2) every other entry point on that
+ * context returns -3 until gpfit_fit_eval_finish has collected it.
  * n_max: stimuli; d_max: masked pixels; d_full_max: pixels of the full image. */
 typedef struct gpfit_ctx gpfit_ctx;
 int gpfit_ctx_create(int device, int64_t n_max, int64_t d_max, int64_t d_full_max, gpfit_ctx** out);

@@ -203,9 +203,14 @@ def g3():
 
 
 # ------------------------------------------------------------------ G4 Estep
-def g4():
-    N, d = 64, 64
+def g4(N=64, store_K=True):
+    """Estep (utils.py:1402-1439) in the reference's eigenbasis, mapped back to the original basis.
+    N = 64 is one 128-leaf of the GPU factorisation; N = 192 / 320 exercise its multi-tile path
+    (two / three 128-tiles, the block-wise L_M^-1 branch).  The larger case omits K~ (it is
+    rebuilt from X by the kernel entry point that G2 pins)."""
+    d = 64
     c = closure_case(N, d, 1e-14)
+    assert c["n_kept"] == N
     th = {k: float(v) for k, v in zip(KEYS, c["theta"])}
     t = tth(th)
     X = torch.from_numpy(c["X"])
@@ -220,9 +225,11 @@ def g4():
     fp = {"logA": torch.tensor(c["logA"]), "lambda0": torch.tensor(c["lambda0"])}
     m_new_b, V_new_b = ref.Estep(r=r, KKtilde_inv=B, m=m_b, f_params=fp, f_mean=f, K_tilde=Kt_b,
                                  K_tilde_inv=torch.diag(1 / ev), update_V_inv=False, alpha=1)
-    save("g4_estep_N64.npz", theta=c["theta"], X=c["X"], r=c["r"], m=c["m"], f=c["f"], logA=c["logA"],
-         B=B.numpy(), eigvals=ev.numpy(), Kt=Kt.numpy(), m_new_b=m_new_b.numpy(), V_new_b=V_new_b.numpy(),
-         m_new=(B @ m_new_b).numpy(), V_new=(B @ V_new_b @ B.T).numpy())
+    out = dict(theta=c["theta"], X=c["X"], r=c["r"], m=c["m"], f=c["f"], logA=c["logA"],
+               m_new=(B @ m_new_b).numpy(), V_new=(B @ V_new_b @ B.T).numpy())
+    if store_K:
+        out.update(B=B.numpy(), eigvals=ev.numpy(), Kt=Kt.numpy(), m_new_b=m_new_b.numpy(), V_new_b=V_new_b.numpy())
+    save(f"g4_estep_N{N}.npz", **out)
 
 
 # ------------------------------------------------------------------ G5 predict
@@ -274,6 +281,8 @@ def g6(tol, name, dup=0, ntilde=None):
     Rt = torch.from_numpy(np.random.default_rng(5).poisson(0.7, (4, 6, 1)).astype(np.float64))
     with contextlib.redirect_stdout(buf), warnings_off():
         _, R_pred, _, _ = ref.test(Xs, Rt, X_train=X, at_iteration=None, **fit)
+        # the at_iteration branch (utils.py:358-386): kernel / eigenbasis rebuilt from the tracked theta
+        _, R_pred_it2, _, _ = ref.test(Xs, Rt, X_train=X, at_iteration=2, **fit)
     print(name, "kept", fit["B"].shape[1], "of", ntilde)
     save(name, tol=tol, N=N, d=d, dup=dup, ntilde=ntilde, X=X.numpy(), r=r_np, theta0=thvec(th),
          maxiter=4, nEstep=2, nMstep=3, nFparamstep=3,
@@ -284,7 +293,72 @@ def g6(tol, name, dup=0, ntilde=None):
          theta_final=np.array([float(fit["hyperparams_tuple"][0][k]) for k in KEYS]),
          logA_final=float(fit["f_params"]["logA"]), lambda0_final=float(fit["f_params"]["lambda0"]),
          m_b=fit["m_b"].numpy(), V_b=fit["V_b"].numpy(), B=fit["B"].numpy(), n_kept=fit["B"].shape[1],
-         Xstar=Xs.numpy(), R_pred=R_pred.numpy())
+         Xstar=Xs.numpy(), R_pred=R_pred.numpy(), R_pred_it2=R_pred_it2.numpy())
+    ref.EIGVAL_TOL = 1e-4
+
+
+# ------------------------------------------------------------------ G10 varGP error roll-back
+class FaultInjected(RuntimeError):
+    pass
+
+
+def inject_localker_fault(mod, nth):
+    """Replace ``mod.localker`` by a wrapper that raises on its nth call with grad=False (the kernel
+    rebuild at the top of an EM iteration, utils.py:1803; the M-step closure asks for grad=True).
+    Returns the restore function.  Shared with tests/test_gpu_dropin.py (fault injection on the
+    drop-in module through the same module-level name)."""
+    orig = mod.localker
+    count = [0]
+
+    def wrapper(*a, **kw):
+        grad = kw.get("grad", a[4] if len(a) > 4 else False)
+        if not grad:
+            count[0] += 1
+            if count[0] == nth:
+                raise FaultInjected(f"injected fault in localker call {nth}")
+        return orig(*a, **kw)
+
+    mod.localker = wrapper
+    return lambda: setattr(mod, "localker", orig)
+
+
+def g10():
+    """varGP's error roll-back (utils.py:2127-2231): an exception at the kernel rebuild of EM
+    iteration 3 (third grad=False localker call) makes the reference fall back to the state tracked
+    at iteration 2, rebuild the kernels there, overwrite the last tracked loss and return
+    err_dict instead of raising."""
+    ref.EIGVAL_TOL = 1e-14
+    N, d = 128, 64
+    X = torch.from_numpy(syn.stimuli(N, d, seed=0))
+    r_np, _ = syn.cell_inputs(N)
+    r = torch.from_numpy(r_np)
+    th = syn.theta0()
+    fit_parameters = {"ntilde": N, "maxiter": 6, "nEstep": 2, "nMstep": 3, "nFparamstep": 3,
+                      "kernfun": "acosker", "cellid": 0, "n_px_side": 8, "display_hyper": False}
+    args = {"fit_parameters": fit_parameters, "xtilde": X.clone(), "hyperparams_tuple": (tth(th), lower, upper),
+            "f_params": {"logA": torch.tensor(syn.F_PARAMS["logA"]), "lambda0": torch.tensor(syn.F_PARAMS["lambda0"])}}
+    restore = inject_localker_fault(ref, 3)
+    try:
+        with contextlib.redirect_stdout(io.StringIO()), warnings_off():
+            fit, err = ref.varGP(X, r, **args)
+    finally:
+        restore()
+    assert err["is_error"] and isinstance(err["error"], FaultInjected), err
+    vt = fit["values_track"]
+    B = fit["B"]
+    print("g10: rolled back to maxiter", fit["fit_parameters"]["maxiter"], "track", vt["loss_track"]["logmarginal"].numpy())
+    save("g10_vargp_rollback_N128.npz", tol=1e-14, N=N, d=d, X=X.numpy(), r=r_np, theta0=thvec(th),
+         maxiter=6, nEstep=2, nMstep=3, nFparamstep=3, fault_call=3,
+         maxiter_after=fit["fit_parameters"]["maxiter"],
+         logmarginal=vt["loss_track"]["logmarginal"].numpy(), loglikelihood=vt["loss_track"]["loglikelihood"].numpy(),
+         KL=vt["loss_track"]["KL"].numpy(),
+         theta_track=np.stack([vt["theta_track"][k].numpy() for k in KEYS]),
+         logA_track=vt["f_par_track"]["logA"].numpy(), lambda0_track=vt["f_par_track"]["lambda0"].numpy(),
+         theta_final=np.array([float(fit["hyperparams_tuple"][0][k]) for k in KEYS]),
+         logA_final=float(fit["f_params"]["logA"]), lambda0_final=float(fit["f_params"]["lambda0"]),
+         n_tracked_V=len(vt["variation_par_track"]["V_b"]),
+         m_orig=(B @ fit["m_b"]).numpy(), V_orig=(B @ fit["V_b"] @ B.T).numpy(), n_kept=B.shape[1],
+         K_tilde=fit["final_kernel"]["K_tilde"].numpy())
     ref.EIGVAL_TOL = 1e-4
 
 
@@ -325,6 +399,18 @@ def g9():
 
 if __name__ == "__main__":
     torch.manual_seed(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "g4":
+        g4(192, store_K=False)
+        g4(320, store_K=False)
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "g6":
+        g6(1e-14, "g6_vargp_full_N128.npz")
+        g6(1e-4, "g6_vargp_trunc_N128.npz", dup=16)
+        g6(1e-4, "g6_vargp_sparse_N128_nt64.npz", ntilde=64)
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "g10":
+        g10()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "g9":
         g9()
         sys.exit(0)
@@ -338,9 +424,12 @@ if __name__ == "__main__":
     g2()
     g3()
     g4()
+    g4(192, store_K=False)
+    g4(320, store_K=False)
     g5()
     g6(1e-14, "g6_vargp_full_N128.npz")
     g6(1e-4, "g6_vargp_trunc_N128.npz", dup=16)
     g6(1e-4, "g6_vargp_sparse_N128_nt64.npz", ntilde=64)
     g8()
     g9()
+    g10()

@@ -209,6 +209,56 @@ def test_estep_general_and_fused(gp):
             gp.Estep(r=r, KKtilde_inv=B, m=m_b, f_params=fp, f_mean=f, K_tilde=torch.diag(ev), alpha=0.5)
 
 
+def _fused_estep(gp, Kt, r, m, f, logA):
+    from gaussian_processes_amd import _lib
+    n = Kt.shape[0]
+    eng = gp.get_engine(n, 1)
+    m_new = torch.empty(n, dtype=torch.float64, device="cuda")
+    V_new = torch.empty((n, n), dtype=torch.float64, device="cuda")
+    rc = _lib.load().gpfit_estep(eng._ctx, gp._stream(), Kt.data_ptr(), Kt.stride(0), n, r.data_ptr(), m.data_ptr(),
+                                 f.data_ptr(), float(logA), m_new.data_ptr(), V_new.data_ptr(), V_new.stride(0))
+    assert rc == 0, _lib.last_error()
+    return m_new, V_new
+
+
+@pytest.mark.parametrize("N", [192, 320])
+def test_fused_estep_multi_tile_matches_reference(gp, N):
+    """gpfit_estep above one 128-leaf (np = 256 / 384: the recursion, the block-wise L_M^-1 solves
+    T1 / T2 and the ragged last tile) against the real reference's Estep (fixtures G4 at N = 192, 320,
+    mapped from its eigenbasis back to the original basis)."""
+    g = load_golden(f"g4_estep_N{N}.npz")
+    th = tth(g["theta"])
+    C, mask = gp.localker(th, UPPER, LOWER, 8)
+    X = T(g["X"])[:, mask].contiguous()
+    Kt = gp.acosker(th, X, X, C=C)
+    m_new, V_new = _fused_estep(gp, Kt, T(g["r"]), T(g["m"]), T(g["f"]), float(g["logA"]))
+    assert relerr(m_new.cpu().numpy(), g["m_new"]) < 1e-9
+    assert relerr(V_new.cpu().numpy(), g["V_new"]) < 1e-9
+    assert torch.equal(V_new, V_new.T)
+
+
+@pytest.mark.parametrize("N,d", [(1000, 64), (4096, 128)])
+def test_fused_estep_matches_oracle_at_scale(gp, N, d):
+    """gpfit_estep against the CPU oracle (estep_cholesky, pinned to the reference by G4) at a
+    ragged size (N = 1000: np = 1024, identity padding inside the last tile) and at BASELINE
+    configs[1]'s N = 4096 (three recursion levels above the leaf, stream-K launches)."""
+    grid = syn.grid_for(d)
+    th = {k: float(v) for k, v in syn.theta_eval().items()}
+    Xc = torch.from_numpy(syn.stimuli(N, d))
+    r_np, m_np = syn.cell_inputs(N)
+    Cc, maskc = orc.spatial_metric(th, LOWER, UPPER, grid)
+    Kc = orc.arccos_gram(th, Xc[:, maskc], Xc[:, maskc], Cc)
+    rc, mc = torch.from_numpy(r_np), torch.from_numpy(m_np)
+    lam_var = 0.5 * torch.diagonal(Kc)
+    fc = orc.rate_mean(syn.F_PARAMS["logA"], syn.F_PARAMS["lambda0"], mc, lam_var)
+    logA = float(np.log(0.4))      # a larger A than the fit's initial one: S K S is far from negligible against I
+    m_o, V_o = orc.estep_cholesky(Kc, rc, mc, fc, logA)
+    m_new, V_new = _fused_estep(gp, Kc.cuda(), rc.cuda(), mc.cuda(), fc.cuda(), logA)
+    assert relerr(m_new.cpu().numpy(), m_o.numpy()) < 1e-9
+    assert relerr(V_new.cpu().numpy(), V_o.numpy()) < 1e-9
+    assert torch.equal(V_new, V_new.T)
+
+
 def test_predict_matches_golden(gp):
     g = load_golden("g5_predict_N64.npz")
     th = tth(g["theta"])
@@ -244,7 +294,7 @@ def test_fparam_functions(gp):
     assert abs(out[1] - float(Lo)) < 1e-11 * abs(float(Lo)) and abs(out[2] - float(do["logA"])) < 1e-10 * abs(out[2])
 
 
-def _run_vargp(gp, g):
+def _run_vargp(gp, g, at_iteration=None):
     N, d = int(g["N"]), int(g["d"])
     X = T(g["X"])
     r = T(g["r"])
@@ -263,7 +313,7 @@ def _run_vargp(gp, g):
             warnings.simplefilter("ignore")
             fit, err = gp.varGP(X, r, **args)
             Rt = T(np.random.default_rng(5).poisson(0.7, (4, 6, 1)).astype(np.float64))
-            _, R_pred, _, _ = gp.test(T(g["Xstar"]), Rt, X_train=X, at_iteration=None, **fit)
+            _, R_pred, _, _ = gp.test(T(g["Xstar"]), Rt, X_train=X, at_iteration=at_iteration, **fit)
     finally:
         gp.EIGVAL_TOL = old
     return fit, err, R_pred
@@ -288,6 +338,108 @@ def test_vargp_end_to_end_matches_reference(gp, name, tol_track):
     for key in ("fit_parameters", "final_kernel", "err_dict", "xtilde", "hyperparams_tuple", "f_params", "m_b", "V_b",
                 "C", "mask", "K_tilde_b", "K_tilde_inv_b", "K_b", "Kvec", "B", "values_track"):
         assert key in fit
+
+
+@pytest.mark.parametrize("name", ["g6_vargp_full_N128.npz", "g6_vargp_trunc_N128.npz", "g6_vargp_sparse_N128_nt64.npz"])
+def test_predict_at_iteration_matches_reference(gp, name):
+    """test(..., at_iteration=2) (utils.py:358-386): prediction from the state tracked at EM
+    iteration 2 -- theta, (m_b, V_b), logA, lambda0 from values_track, kernel and eigenbasis rebuilt
+    from that theta -- against the reference's own R_pred for the same call."""
+    g = load_golden(name)
+    fit, err, R_pred = _run_vargp(gp, g, at_iteration=2)
+    assert not err["is_error"], err
+    assert relerr(R_pred.cpu().numpy(), g["R_pred_it2"]) < 1e-4
+    assert relerr(R_pred.cpu().numpy(), g["R_pred"]) > 1e-3      # it really is a different state
+
+
+def test_vargp_error_rollback_matches_reference(gp):
+    """varGP's error branch (utils.py:2127-2231): a fault injected into the kernel rebuild of EM
+    iteration 3 (the third grad=False call of the module-level ``localker``, the same injection
+    point the fixture generator used on the real reference) must not raise; the fit rolls back to
+    the state tracked at iteration 2, rebuilds the kernels there, overwrites the last tracked loss
+    and returns err_dict -- same truncated tracks, same final theta / f-params / (m, V) as the
+    reference (fixture G10)."""
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+    g = load_golden("g10_vargp_rollback_N128.npz")
+    N = int(g["N"])
+    X, r = T(g["X"]), T(g["r"])
+    fit_parameters = {"ntilde": N, "maxiter": int(g["maxiter"]), "nEstep": int(g["nEstep"]), "nMstep": int(g["nMstep"]),
+                      "nFparamstep": int(g["nFparamstep"]), "kernfun": "acosker", "cellid": 0, "n_px_side": 8,
+                      "display_hyper": False}
+    args = {"fit_parameters": fit_parameters, "xtilde": X.clone(), "hyperparams_tuple": (tth(g["theta0"]), LOWER, UPPER),
+            "f_params": {"logA": torch.tensor(syn.F_PARAMS["logA"], dtype=torch.float64),
+                         "lambda0": torch.tensor(syn.F_PARAMS["lambda0"], dtype=torch.float64)}}
+
+    class Fault(RuntimeError):
+        pass
+
+    orig, count = gp.localker, [0]
+
+    def faulty(*a, **kw):
+        if not kw.get("grad", a[4] if len(a) > 4 else False):
+            count[0] += 1
+            if count[0] == int(g["fault_call"]):
+                raise Fault("injected")
+        return orig(*a, **kw)
+
+    old = gp.EIGVAL_TOL
+    gp.EIGVAL_TOL = float(g["tol"])
+    gp.localker = faulty
+    try:
+        with contextlib.redirect_stdout(io.StringIO()), warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            fit, err = gp.varGP(X, r, **args)
+    finally:
+        gp.localker = orig
+        gp.EIGVAL_TOL = old
+    assert err["is_error"] and isinstance(err["error"], Fault)
+    assert fit["err_dict"] is err
+    assert fit["fit_parameters"]["maxiter"] == int(g["maxiter_after"])
+    vt = fit["values_track"]
+    assert len(vt["loss_track"]["logmarginal"]) == len(g["logmarginal"])
+    assert len(vt["variation_par_track"]["V_b"]) == int(g["n_tracked_V"])
+    assert relerr(vt["loss_track"]["logmarginal"].numpy(), g["logmarginal"]) < 1e-6
+    assert relerr(vt["loss_track"]["KL"].numpy(), g["KL"]) < 1e-5
+    assert relerr(vt["loss_track"]["loglikelihood"].numpy(), g["loglikelihood"]) < 1e-6
+    th_final = np.array([float(fit["hyperparams_tuple"][0][k]) for k in KEYS])
+    assert np.abs(th_final - g["theta_final"]).max() < 1e-4
+    assert np.abs(np.stack([vt["theta_track"][k].numpy() for k in KEYS]) - g["theta_track"]).max() < 1e-4
+    assert abs(float(fit["f_params"]["logA"]) - float(g["logA_final"])) < 1e-4
+    assert abs(float(fit["f_params"]["lambda0"]) - float(g["lambda0_final"])) < 1e-4
+    B = fit["B"]
+    assert B.shape[1] == int(g["n_kept"])
+    assert relerr(gp.matmul(B, fit["m_b"]).cpu().numpy(), g["m_orig"]) < 1e-4
+    assert relerr(gp.matmul(B, gp.matmul(fit["V_b"], B, transB=True)).cpu().numpy(), g["V_orig"]) < 1e-4
+    assert relerr(fit["final_kernel"]["K_tilde"].cpu().numpy(), g["K_tilde"]) < 1e-5
+
+
+def test_vargp_error_in_first_iteration_returns_err_dict(gp):
+    """utils.py:2134-2138 / 2168-2172 re-raise when at most one iteration completed, but the
+    ``return`` inside the reference's ``finally`` (utils.py:2316) swallows it: run on the real
+    reference, a NaN response in the first E-step comes back as ``(fit_model, err_dict)`` with
+    ``is_error``, a ValueError and ``maxiter == 1`` (checked in the build container).  Same here."""
+    g = load_golden("g10_vargp_rollback_N128.npz")
+    N = int(g["N"])
+    X, r = T(g["X"]), T(g["r"])
+    fit_parameters = {"ntilde": N, "maxiter": 4, "nEstep": 1, "nMstep": 1, "nFparamstep": 1, "kernfun": "acosker",
+                      "cellid": 0, "n_px_side": 8, "display_hyper": False}
+    bad_r = r.clone()
+    bad_r[3] = float("nan")       # NaN rates in the first E-step (utils.py:1923-1924)
+    args = {"fit_parameters": fit_parameters, "xtilde": X.clone(), "hyperparams_tuple": (tth(g["theta0"]), LOWER, UPPER),
+            "f_params": {"logA": torch.tensor(syn.F_PARAMS["logA"], dtype=torch.float64),
+                         "lambda0": torch.tensor(syn.F_PARAMS["lambda0"], dtype=torch.float64)}}
+    old = gp.EIGVAL_TOL
+    gp.EIGVAL_TOL = 1e-14
+    try:
+        with contextlib.redirect_stdout(io.StringIO()), warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            fit, err = gp.varGP(X, bad_r, **args)
+    finally:
+        gp.EIGVAL_TOL = old
+    assert err["is_error"] and isinstance(err["error"], ValueError) and "Nan in f_mean" in str(err["error"])
+    assert fit["fit_parameters"]["maxiter"] == 1
+    assert len(fit["values_track"]["loss_track"]["logmarginal"]) == 1
 
 
 def test_nd_utility_matches_reference(gp):

@@ -185,6 +185,20 @@ def test_headline_deterministic_and_permutation_invariant(dev, headline):
     assert np.abs(ga - gp).max() <= 1e-8 * np.abs(ga).max()
 
 
+def test_headline_N8192_matches_oracle(dev, headline):
+    """The headline size itself (BASELINE configs[2]: N=8192, d=256, fp64) against the CPU oracle's
+    Cholesky restatement on the same seeded inputs (about 15 s of host time): loss, log-likelihood,
+    KL, all six gradients and the three posterior vectors, at the same tolerances as every other
+    parity test.  V is taken from the GPU fixture so that both sides see the same bits."""
+    grid, X, r, m, V = headline
+    th1 = syn.theta_eval()
+    torch.set_num_threads(max(1, min(32, len(__import__("os").sched_getaffinity(0)))))
+    loss, grad, p = orc.mstep_closure_cholesky(th1, LOWER, UPPER, grid, X.cpu(), r.cpu(), m.cpu(), V.cpu(), LOGA, LAM0,
+                                               want_parts=True)
+    res = engine(8192, 256).fit_eval(th1, LOWER, UPPER, grid, X, r, m, V, LOGA, LAM0)
+    assert_close(res, loss, p["loglik"], p["KL"], grad, p["lam_m"], p["lam_var"], p["f"])
+
+
 def test_headline_gradient_matches_finite_difference(dev, headline):
     """Directional derivative of the loss along a fixed direction vs central differences.
     (The reference's analytic dK ignores the +1e-7 and the clip in cos(delta), utils.py:984 vs

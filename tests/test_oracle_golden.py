@@ -155,6 +155,20 @@ def test_g4_estep():
     assert relerr(V_new, g["V_new"]) < 1e-9
 
 
+@pytest.mark.parametrize("N", [192, 320])
+def test_g4_estep_multi_tile_sizes(N):
+    """The original-basis restatement against the reference's Estep at sizes that span two / three
+    128-tiles of the GPU factorisation (K~ rebuilt from X by the oracle's own kernel, pinned by G2)."""
+    g = load_golden(f"g4_estep_N{N}.npz")
+    th = thd(g["theta"])
+    C, mask = orc.spatial_metric(th, LOWER, UPPER, 8)
+    X = T(g["X"])[:, mask]
+    Kt = orc.arccos_gram(th, X, X, C)
+    m_new, V_new = orc.estep_cholesky(Kt, T(g["r"]), T(g["m"]), T(g["f"]), float(g["logA"]))
+    assert relerr(m_new, g["m_new"]) < 1e-9
+    assert relerr(V_new, g["V_new"]) < 1e-9
+
+
 def test_g5_predict():
     g = load_golden("g5_predict_N64.npz")
     th = thd(g["theta"])
