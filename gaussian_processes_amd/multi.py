@@ -35,6 +35,44 @@ def broadcast_stimuli(X: torch.Tensor | None, shape, device, src: int = 0) -> to
     return X
 
 
+def broadcast_state(r, m, V, n: int, device, dtype=torch.float64, src: int = 0):
+    """Per-cell state shared by every unit of a hyperparameter grid (BASELINE configs[4]: 512 theta
+    points, one cell): ``r``, ``m`` (n each) and ``V`` (n x n) from rank ``src`` to all ranks.
+
+    ``r`` and ``m`` are KiB-sized: one flat broadcast each.  ``V`` is bandwidth-bound (256 MiB at
+    N=8192 fp32, 512 MiB fp64) and xGMI is point-to-point, so a ring / tree broadcast would be
+    bound by one ~153 GB/s link; instead rank ``src`` SCATTERS ``world`` row blocks (each of its
+    seven links carries 1/world of the payload) and the ranks ALL-GATHER them (every link carries
+    one block in each direction): SURVEY.md section 5 / 8(e).  Ranks other than ``src`` pass None."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        assert r is not None and m is not None and V is not None
+        return r.to(device=device, dtype=dtype), m.to(device=device, dtype=dtype), V.to(device=device, dtype=dtype)
+    world, rank = dist.get_world_size(), dist.get_rank()
+    vecs = torch.empty((2, n), dtype=dtype, device=device)
+    if rank == src:
+        vecs[0], vecs[1] = r.to(device=device, dtype=dtype), m.to(device=device, dtype=dtype)
+    dist.broadcast(vecs, src=src)
+    rows = (n + world - 1) // world                      # row block per rank (the last one zero padded)
+    block = torch.empty((rows, n), dtype=dtype, device=device)
+    if rank == src:
+        Vp = torch.zeros((rows * world, n), dtype=dtype, device=device)
+        Vp[:n] = V.to(device=device, dtype=dtype)
+        dist.scatter(block, [Vp[i * rows:(i + 1) * rows] for i in range(world)], src=src)
+        del Vp
+    else:
+        dist.scatter(block, None, src=src)
+    full = torch.empty((rows * world, n), dtype=dtype, device=device)
+    if dist.get_backend() == "nccl":
+        dist.all_gather_into_tensor(full, block)
+    else:
+        parts = [full[i * rows:(i + 1) * rows] for i in range(world)]
+        gathered = [torch.empty_like(block) for _ in range(world)]
+        dist.all_gather(gathered, block)
+        for dst, g in zip(parts, gathered):
+            dst.copy_(g)
+    return vecs[0].contiguous(), vecs[1].contiguous(), full[:n]
+
+
 def evaluate_units(units: Sequence[int], eval_fn: Callable[[int], Sequence[float]], device) -> torch.Tensor:
     """Run ``eval_fn(u) -> (loss, g0..g5)`` for the local units, back to back."""
     out = torch.zeros((len(units), RESULT_WIDTH), dtype=torch.float64, device=device)

@@ -41,6 +41,47 @@ def worker(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
+def state_worker(rank, world, port, out_dir):
+    """theta-grid configuration: one cell's (r, m, V) from rank 0 to all ranks (scatter + all-gather
+    of V), then the grid points sharded cyclically; every rank must hold rank 0's exact bits."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    n = 37                                # not a multiple of the world size: the last row block is padded
+    if rank == 0:
+        g = torch.Generator().manual_seed(5)
+        r0 = torch.poisson(torch.full((n,), 0.7, dtype=torch.float64), generator=g)
+        m0 = torch.randn(n, dtype=torch.float64, generator=g)
+        A = torch.randn(n, n, dtype=torch.float64, generator=g)
+        V0 = A @ A.T + n * torch.eye(n, dtype=torch.float64)
+    else:
+        r0 = m0 = V0 = None
+    for dtype in (torch.float64, torch.float32):
+        r, m, V = multi.broadcast_state(r0, m0, V0, n, torch.device("cpu"), dtype=dtype)
+        assert r.shape == (n,) and m.shape == (n,) and V.shape == (n, n) and V.dtype == dtype
+        np.save(os.path.join(out_dir, f"state_{rank}_{'f64' if dtype == torch.float64 else 'f32'}.npy"),
+                torch.cat([r, m, V.reshape(-1)]).double().numpy())
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_broadcast_state(tmp_path):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(state_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    for tag in ("f64", "f32"):
+        a, b = np.load(tmp_path / f"state_0_{tag}.npy"), np.load(tmp_path / f"state_1_{tag}.npy")
+        assert np.array_equal(a, b), f"ranks hold different {tag} state"
+    n = 37
+    g = torch.Generator().manual_seed(5)
+    r0 = torch.poisson(torch.full((n,), 0.7, dtype=torch.float64), generator=g)
+    assert np.array_equal(np.load(tmp_path / "state_0_f64.npy")[:n], r0.numpy())
+    # single process: pass-through
+    r, m, V = multi.broadcast_state(r0, r0, torch.eye(n, dtype=torch.float64), n, torch.device("cpu"))
+    assert torch.equal(r, r0) and torch.equal(V, torch.eye(n, dtype=torch.float64))
+
+
 def test_partition_is_a_cyclic_cover():
     for n, w in [(64, 8), (5, 2), (7, 4), (3, 8)]:
         parts = [multi.partition(n, w, r) for r in range(w)]

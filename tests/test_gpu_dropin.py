@@ -442,6 +442,78 @@ def test_vargp_error_in_first_iteration_returns_err_dict(gp):
     assert len(fit["values_track"]["loss_track"]["logmarginal"]) == 1
 
 
+def test_second_thread_gets_its_own_context(gp):
+    """one_cell_active_training.ipynb:2446-2461 scores candidates (acosker + lambda_moments) on a
+    second threading.Thread while the main thread keeps calling into the library.  A context is not
+    re-entrant, so the pool hands every thread its own; both threads' results must equal the
+    single-threaded ones bit for bit."""
+    import threading
+    g = load_golden("g5_predict_N64.npz")
+    th = tth(g["theta"])
+    C, mask = gp.localker(th, UPPER, LOWER, 8)
+    X = T(g["X"])[:, mask].contiguous()
+    rng = np.random.default_rng(21)
+    Xs = T(rng.standard_normal((700, g["X"].shape[1])))[:, mask].contiguous()
+    ref_K = gp.acosker(th, Xs, x2=X, C=C)
+    ref_Kt = gp.acosker(th, X, X, C=C)
+    main_engine = gp.get_engine(700, int(mask.sum()))
+    out, errors = {}, []
+
+    def scorer():
+        try:
+            torch.cuda.set_device(0)
+            out["engine"] = gp.get_engine(700, int(mask.sum()))
+            for _ in range(20):
+                out["K"] = gp.acosker(th, Xs, x2=X, C=C)
+                out["Kvec"] = gp.acosker(th, Xs, x2=None, C=C, diag=True)
+        except Exception as e:  # surfaced in the main thread below
+            errors.append(e)
+
+    t = threading.Thread(target=scorer)
+    t.start()
+    for _ in range(20):
+        Kt = gp.acosker(th, X, X, C=C)
+        L, Li, logdet, info = gp.cholesky(Kt, want_inverse=True)
+    t.join()
+    assert not errors, errors
+    assert out["engine"] is not main_engine
+    assert torch.equal(out["K"], ref_K) and torch.equal(Kt, ref_Kt) and info == 0
+
+
+def test_pending_evaluation_blocks_other_entry_points():
+    """While an asynchronous evaluation is in flight on a context every other entry point on it
+    must refuse (-3) instead of overwriting the workspace; after the collect they work again."""
+    from gaussian_processes_amd import _lib
+    from gaussian_processes_amd.engine import GPFitEngine
+    N, d = 256, 64
+    grid = syn.grid_for(d)
+    dev = torch.device("cuda:0")
+    X = T(syn.stimuli(N, d))
+    r_np, m_np = syn.cell_inputs(N)
+    th0, th1 = syn.theta0(), syn.theta_eval()
+    C0, mask0 = orc.spatial_metric(th0, LOWER, UPPER, grid)
+    V = (0.5 * orc.arccos_gram(th0, X.cpu()[:, mask0], X.cpu()[:, mask0], C0)).to(dev)
+    eng = GPFitEngine(N, d)
+    lib = _lib.load()
+    r, m = T(r_np), T(m_np)
+    sync = eng.fit_eval(th1, LOWER, UPPER, grid, X, r, m, V, syn.F_PARAMS["logA"], syn.F_PARAMS["lambda0"])
+    ticket = eng.fit_eval_async(th1, LOWER, UPPER, grid, X, r, m, V, syn.F_PARAMS["logA"], syn.F_PARAMS["lambda0"])
+    out = (__import__("ctypes").c_double * 7)()
+    stream = __import__("ctypes").c_void_p(torch.cuda.current_stream().cuda_stream)
+    rc = lib.gpfit_fparam_eval(eng._ctx, stream, m.data_ptr(), m.data_ptr(), r.data_ptr(), N, 0.0, 0, 0.0, None, out)
+    assert rc == -3 and "pending" in _lib.last_error()
+    m_new = torch.empty(N, dtype=torch.float64, device=dev)
+    V_new = torch.empty((N, N), dtype=torch.float64, device=dev)
+    rc = lib.gpfit_estep(eng._ctx, stream, V.data_ptr(), V.stride(0), N, r.data_ptr(), m.data_ptr(), m.data_ptr(), 0.0,
+                         m_new.data_ptr(), V_new.data_ptr(), V_new.stride(0))
+    assert rc == -3
+    res = eng.fit_eval_finish(ticket)
+    assert res["loss"] == sync["loss"] and res["grad"] == sync["grad"]
+    rc = lib.gpfit_fparam_eval(eng._ctx, stream, m.data_ptr(), m.data_ptr(), r.data_ptr(), N, 0.0, 0, 0.0, None, out)
+    assert rc == 0
+    eng.close()
+
+
 def test_nd_utility_matches_reference(gp):
     """Active-learning utility: device kernel incl. Lambert W against the real
     reference's nd_utility (scipy Lambert W) on the G8 fixture -- values from 7e-8 to 6e7, entries
