@@ -32,6 +32,7 @@ _SIGS = {
     "gpfit_fparam_eval": (i32, [vp, vp, vp, vp, vp, i64, f64, i32, f64, vp, pd]),
     "gpfit_set_profile": (i32, [vp, i32]),
     "gpfit_get_profile": (i32, [vp, pd]),
+    "gpfit_get_phases": (i32, [vp, pd]),
     "gpfit_last_enqueue_ms": (f64, [vp]),
     "gpfit_fit_eval_f32": (i32, [vp, vp, pd, pd, pd, i32, i32, vp, i64, i64, vp, vp, vp, i64, f64, f64, i32, pd,
                                  vp, vp, vp]),

@@ -59,6 +59,12 @@ struct GemmArgsT {
   int workspace;             // stream-K partial-tile workspace to use (0 main stream, 1 aux stream)
   void* sk_ws;               // caller-owned stream-K workspace (>= SK_WS_BYTES); nullptr: process-wide one
   int tile_limit;            // >0: launch only the first tile_limit tiles of the walk (stream-K head)
+  int half_occ;              // 1: pad the launch with unused dynamic LDS so that only ONE workgroup of it fits on
+                             // a CU: a long GEMM off the critical path then leaves half of every CU (79 KiB
+                             // of LDS, 320 VGPRs) to the latency-bound kernels of the critical chain instead
+                             // of holding every workgroup slot of the chip for its whole duration
+  const int* sched;          // device tile table of an XCD-aware schedule (gemm_sched.hip), or nullptr
+  int sched_blocks;          // its length = the grid size
 };
 using GemmArgs = GemmArgsT<double>;
 
@@ -72,6 +78,8 @@ template <typename R> int gemm_pick_tile(const GemmArgsT<R>& a);   // block tile
 // stream-K schedule for large 128-tile launches (gemm_streamk.hip): 0 issued, 1 not applicable
 template <typename R> int launch_gemm_streamk(const GemmArgsT<R>& a, hipStream_t s);
 template <typename R> int launch_gemm_plain(const GemmArgsT<R>& a, hipStream_t s);  // data-parallel launch, no stream-K
+// XCD-aware data-parallel schedule (gemm_sched.hip): 0 issued, 1 not applicable.  Walk bit 3 asks for it.
+template <typename R> int launch_gemm_xcd(const GemmArgsT<R>& a, hipStream_t s);
 
 // Arc-cosine Gram matrix from the k-major, zero-padded operands XCt[Kd][ld1], Xt[Kd][ld2]:
 //   G = XCt^T Xt + s0^2 ; c = clip(G/(q1 q2 + 1e-7)) ; K = q1 q2 J(c)

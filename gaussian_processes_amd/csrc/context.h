@@ -22,7 +22,12 @@ struct gpfit_ctx {
          *q2 = nullptr, *dq1 = nullptr, *dq2 = nullptr, *hvec = nullptr;
   double *upart = nullptr, *vpart = nullptr, *sumA_part = nullptr, *frob_part = nullptr, *trmv_part = nullptr;
   double* rect_part = nullptr;  // (np/64)^2 per-tile sums of the rectangular adjoint
-  void* sk_ws[2] = {nullptr, nullptr};  // stream-K partial-tile workspaces (main / aux stream)
+  void* sk_ws[4] = {nullptr, nullptr, nullptr, nullptr};  // stream-K partial-tile workspaces (main / aux / two side streams)
+  // look-ahead: the first product of every inverse merge (tmp = L21 Li11) runs on a side stream of
+  // its chain while the second half of the block is being factored (fit.hip:potrf_rec)
+  hipStream_t side[2] = {nullptr, nullptr};
+  std::vector<hipEvent_t> side_ev[2];
+  int side_ev_next[2] = {0, 0};
   double* scal = nullptr;       // device scalars [64]
   double* scal_host = nullptr;  // pinned [64]
   int* pix = nullptr;           // device [dfull_cap]
@@ -38,6 +43,11 @@ struct gpfit_ctx {
   std::vector<ProfRec> prof;
   std::vector<hipEvent_t> ev_pool;
   double prof_out[16] = {0};
+  // profile == 2: phase timing only (eight events per fit, none inside the factorisations): 0 start,
+  // 1 kernel build + moments done (fork), 2 K~ chain done, 3 V chain done (aux stream), 4 T and its
+  // norm done, 5 Q = I - T T^T done, 6 two-sided product done, 7 end
+  hipEvent_t phase_ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  bool phase_valid = false;
   double last_enqueue_ms = 0.0;  // host time spent enqueuing the last fit_eval
   // evaluation enqueued but not yet collected (gpfit_fit_eval with the async flag / _finish)
   struct Pending { bool active = false; hipStream_t stream = nullptr; double A = 0, lambda0 = 0, sigma0 = 0;
@@ -94,6 +104,11 @@ struct CholBufsT {
   int* info;
   int ws = 0;   // stream-K workspace id (1 for the factorisation running on the aux stream)
   void* sk_ws = nullptr;  // that workspace (owned by the context)
+  // optional look-ahead resources of this chain (nullptr / 0: everything on the one stream)
+  gpfit_ctx* ctx = nullptr;
+  int chain = 0;           // index into ctx->side / side_ev
+  int side_min = 0;        // blocks of at least this size put their merge product on the side stream
+  int half_occ = 0;        // bit 0: this chain's own 128-tile launches run one workgroup per CU; bit 1: its side-stream products do
 };
 using CholBufs = CholBufsT<double>;
 // Recursive blocked Cholesky of the n x n diagonal block at offset r0 (n a multiple of 128),

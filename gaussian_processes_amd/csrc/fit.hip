@@ -45,7 +45,7 @@ static hipEvent_t prof_event(gpfit_ctx* c) {
 }
 
 void prof_begin(gpfit_ctx* c) {
-  if (c->profile) {
+  if (c->profile == 1) {
     g_prof = c;
     c->prof.clear();
   }
@@ -112,7 +112,7 @@ double gemm_flops(const GemmArgsT<R>& g) {
 template <typename R>
 static int gemm(hipStream_t s, int a_kmajor, int b_kmajor, int M, int N, int K, double alpha, const R* A,
                 int64_t lda, const R* B, int64_t ldb, double beta, R* C, int64_t ldc, int out_lower, int a_tri,
-                int b_tri, int reverse = 0, int ws = 0, void* sk_ws = nullptr, bool plain = false) {
+                int b_tri, int reverse = 0, int ws = 0, void* sk_ws = nullptr, bool plain = false, int half_occ = 0) {
   GemmArgsT<R> g{};
   g.A = A; g.B = B; g.C = C;
   g.lda = lda; g.ldb = ldb; g.ldc = ldc;
@@ -121,9 +121,10 @@ static int gemm(hipStream_t s, int a_kmajor, int b_kmajor, int M, int N, int K, 
   g.a_kmajor = a_kmajor; g.b_kmajor = b_kmajor;
   g.out_lower = out_lower; g.a_tri = a_tri; g.b_tri = b_tri;
   g.batch = 1; g.split_k = 1; g.reverse = reverse; g.workspace = ws; g.sk_ws = sk_ws ? sk_ws : g_main_sk_ws;
+  g.half_occ = half_occ;
   // profile kind 0: the 128-tile kernel family (the dominant kernel), 3: the small-tile instances
   ProfScope ps(s, g_prof ? gemm_flops(g) : 0.0, (g_prof && gemm_pick_tile(g) != TILE) ? 3 : 0);
-  return plain ? launch_gemm_plain(g, s) : launch_gemm(g, s);  // plain: data-parallel, never stream-K
+  return (plain || half_occ) ? launch_gemm_plain(g, s) : launch_gemm(g, s);  // plain: data-parallel, never stream-K
 }
 
 #define GP_TRY(expr)            \
@@ -139,21 +140,48 @@ int potrf_rec(const CholBufsT<R>& B, int r0, int n, int need_inv, hipStream_t s)
   auto at = [&](R* base, int r, int c) { return base + (int64_t)r * ld + c; };
   if (n == TILE) {
     ProfScope ps(s, 0.0, 1);
-    return launch_chol_leaf(at(B.A, r0, r0), ld, at(B.L, r0, r0), ld, at(B.Li, r0, r0), ld, B.info, r0, s);
+    static const bool lds_leaf = getenv("GPFIT_LEAF_LDS") != nullptr;  // tuning knob: the LDS-resident leaf
+    if (lds_leaf) return launch_chol_leaf(at(B.A, r0, r0), ld, at(B.L, r0, r0), ld, at(B.Li, r0, r0), ld, B.info, r0, s);
+    return launch_chol_leaf_reg(at(B.A, r0, r0), ld, at(B.L, r0, r0), ld, at(B.Li, r0, r0), ld, B.info, r0, s);
   }
   const int k = n / TILE;
   const int n1 = ((k + 1) / 2) * TILE, n2 = n - n1;
   const int r1 = r0 + n1;
   GP_TRY(potrf_rec<R>(B, r0, n1, 1, s));
   // L21 = A21 * L11^-T       (trsm as a GEMM against the explicit inverse; op(B) = Li11^T is upper)
-  GP_TRY(gemm<R>(s, 0, 0, n2, n1, n1, 1.0, at(B.A, r1, r0), ld, at(B.Li, r0, r0), ld, 0.0, at(B.L, r1, r0), ld, 0, 0, 2, walks()[0], B.ws, B.sk_ws));
+  GP_TRY(gemm<R>(s, 0, 0, n2, n1, n1, 1.0, at(B.A, r1, r0), ld, at(B.Li, r0, r0), ld, 0.0, at(B.L, r1, r0), ld, 0, 0, 2, walks()[0], B.ws, B.sk_ws, false, B.half_occ & 1));
+  // Look-ahead: tmp = L21 * Li11, the first product of the inverse merge, needs nothing from the second
+  // half, so it runs on the chain's side stream while that half is being factored (its leaves are
+  // latency-bound and leave the chip to it).  Possible because the leaf shares a CU with GEMM workgroups.
+  hipEvent_t joined = nullptr;
+  if (need_inv == 1 && B.ctx && B.side_min > 0 && n >= B.side_min && B.ctx->side[B.chain]) {
+    gpfit_ctx* c = B.ctx;
+    auto next_event = [&]() {
+      auto& pool = c->side_ev[B.chain];
+      int& nx = c->side_ev_next[B.chain];
+      if (nx == (int)pool.size()) {
+        hipEvent_t e = nullptr;
+        (void)hipEventCreateWithFlags(&e, hipEventDisableTiming);
+        pool.push_back(e);
+      }
+      return pool[nx++];
+    };
+    hipStream_t side = c->side[B.chain];
+    hipEvent_t fork = next_event();
+    joined = next_event();
+    GP_HIP(hipEventRecord(fork, s));
+    GP_HIP(hipStreamWaitEvent(side, fork, 0));
+    GP_TRY(gemm<R>(side, 0, 1, n2, n1, n1, 1.0, at(B.L, r1, r0), ld, at(B.Li, r0, r0), ld, 0.0, at(B.Tmp, r1, r0), ld, 0, 0, 1, walks()[1], 2 + B.chain, c->sk_ws[2 + B.chain], false, (B.half_occ >> 1) & 1));
+    GP_HIP(hipEventRecord(joined, side));
+  }
   // A22 -= L21 L21^T          (syrk, lower tiles only)
-  GP_TRY(gemm<R>(s, 0, 0, n2, n2, n1, -1.0, at(B.L, r1, r0), ld, at(B.L, r1, r0), ld, 1.0, at(B.A, r1, r1), ld, 1, 0, 0, 0, B.ws, B.sk_ws));
+  GP_TRY(gemm<R>(s, 0, 0, n2, n2, n1, -1.0, at(B.L, r1, r0), ld, at(B.L, r1, r0), ld, 1.0, at(B.A, r1, r1), ld, 1, 0, 0, 0, B.ws, B.sk_ws, false, B.half_occ & 1));
   GP_TRY(potrf_rec<R>(B, r1, n2, need_inv ? 1 : 0, s));
   if (need_inv == 1) {
     // Li21 = -Li22 * (L21 * Li11)
-    GP_TRY(gemm<R>(s, 0, 1, n2, n1, n1, 1.0, at(B.L, r1, r0), ld, at(B.Li, r0, r0), ld, 0.0, at(B.Tmp, r1, r0), ld, 0, 0, 1, walks()[1], B.ws, B.sk_ws));
-    GP_TRY(gemm<R>(s, 0, 1, n2, n1, n2, -1.0, at(B.Li, r1, r1), ld, at(B.Tmp, r1, r0), ld, 0.0, at(B.Li, r1, r0), ld, 0, 1, 0, walks()[2], B.ws, B.sk_ws));
+    if (joined) GP_HIP(hipStreamWaitEvent(s, joined, 0));
+    else GP_TRY(gemm<R>(s, 0, 1, n2, n1, n1, 1.0, at(B.L, r1, r0), ld, at(B.Li, r0, r0), ld, 0.0, at(B.Tmp, r1, r0), ld, 0, 0, 1, walks()[1], B.ws, B.sk_ws, false, B.half_occ & 1));
+    GP_TRY(gemm<R>(s, 0, 1, n2, n1, n2, -1.0, at(B.Li, r1, r1), ld, at(B.Tmp, r1, r0), ld, 0.0, at(B.Li, r1, r0), ld, 0, 1, 0, walks()[2], B.ws, B.sk_ws, false, B.half_occ & 1));
   }
   return 0;
 }
@@ -306,6 +334,13 @@ static int fit_eval_impl(gpfit_ctx* c, void* stream, const double* theta, const 
   c->cur_n = n; c->cur_np = np; c->cur_d = d; c->cur_dp = dp;
 
   const auto t_host0 = std::chrono::steady_clock::now();
+  auto phase = [&](int i, hipStream_t st) {
+    if (c->profile != 2) return;
+    if (!c->phase_ev[i]) (void)hipEventCreate(&c->phase_ev[i]);
+    (void)hipEventRecord(c->phase_ev[i], st);
+  };
+  c->phase_valid = false;
+  phase(0, s);
   g_main_sk_ws = c->sk_ws[0];
   prof_begin(c);
   struct ProfGuard { gpfit_ctx* c; ~ProfGuard() { prof_end(c); } } prof_guard{c};
@@ -330,14 +365,21 @@ static int fit_eval_impl(gpfit_ctx* c, void* stream, const double* theta, const 
     GP_HIP(hipEventRecord(c->ev_fork, s));
     GP_HIP(hipStreamWaitEvent(sa, c->ev_fork, 0));
   }
+  // tuning knob: smallest block whose inverse-merge product goes to the side stream (0 = never)
+  static const int side_min = getenv("GPFIT_SIDE_MIN") ? atoi(getenv("GPFIT_SIDE_MIN")) : 1024;
+  // tuning knob (bit mask): 1 = the V chain's own 128-tile launches at one workgroup per CU, 2 = the
+  // side-stream products of both chains
+  static const int half_occ = getenv("GPFIT_HALF_OCC") ? atoi(getenv("GPFIT_HALF_OCC")) : 0;
+  c->side_ev_next[0] = c->side_ev_next[1] = 0;
   auto enqueue_v_chain = [&]() -> int {
   if (!reuse_V) {
       c->lv_valid = false;
       GP_TRY(launch_pack_lower(V, ldv, n, RP(c->Vbuf), ld, np, sa));
-      CholBufsT<R> bv{RP(c->Vbuf), RP(c->LVbuf), RP(c->LiVbuf), RP(c->TmpV), ld, c->info + 1, 1, c->sk_ws[1]};
+      CholBufsT<R> bv{RP(c->Vbuf), RP(c->LVbuf), RP(c->LiVbuf), RP(c->TmpV), ld, c->info + 1, 1, c->sk_ws[1], c, 1, side_min, half_occ & 3};
       GP_TRY(potrf_rec<R>(bv, 0, np, false, sa));
       GP_TRY(launch_logdet(RP(c->LVbuf), ld, n, c->scal + 40, sa));
     }
+    phase(3, sa);
     GP_HIP(hipEventRecord(c->ev_join, sa));
     return 0;
   };
@@ -358,13 +400,14 @@ static int fit_eval_impl(gpfit_ctx* c, void* stream, const double* theta, const 
   }
   GP_TRY(launch_moments(RP(c->Kvec), RP(c->q), RP(c->Cos), ld, V, ldv, m, r, n, A, lambda0, RP(c->lam_m), RP(c->lam_var), RP(c->fvec),
                         RP(c->wl), c->scal, s));
+  phase(1, s);
   if (fork_late) {
     GP_HIP(hipEventRecord(c->ev_fork, s));
     GP_HIP(hipStreamWaitEvent(sa, c->ev_fork, 0));
     GP_TRY(enqueue_v_chain());
   }
   {
-    CholBufsT<R> bk{RP(c->Kbuf), RP(c->Lbuf), RP(c->Libuf), RP(c->Tmp), ld, c->info + 0, 0, c->sk_ws[0]};
+    CholBufsT<R> bk{RP(c->Kbuf), RP(c->Lbuf), RP(c->Libuf), RP(c->Tmp), ld, c->info + 0, 0, c->sk_ws[0], c, 0, side_min, half_occ & 2};
     GP_TRY(potrf_rec<R>(bk, 0, np, true, s));
   }
   GP_TRY(launch_logdet(RP(c->Lbuf), ld, n, c->scal + 3, s));
@@ -372,6 +415,7 @@ static int fit_eval_impl(gpfit_ctx* c, void* stream, const double* theta, const 
   GP_TRY(launch_dot(RP(c->yv), RP(c->yv), np, c->scal + 6, s));                  // m^T K~^-1 m
   GP_TRY(launch_trmv_lower_t(RP(c->Libuf), ld, np, RP(c->yv), RP(c->bv), c->trmv_part, s));  // b = K~^-1 m
 
+  phase(2, s);
   // ---- join: everything that needs both factors
   GP_HIP(hipStreamWaitEvent(s, c->ev_join, 0));
   // T = L^-1 L_V (lower x lower -> lower);  tr(K~^-1 V) = ||T||_F^2
@@ -383,6 +427,7 @@ static int fit_eval_impl(gpfit_ctx* c, void* stream, const double* theta, const 
                    dp ? t_plain_walk : walks()[3], 0, nullptr, dp));
   }
   GP_TRY(launch_frob_lower(RP(c->Tbuf), ld, np, c->scal + 5, c->frob_part, s));
+  phase(4, s);
 
   if (want_grad) {
     // W = 1/2 (K~^-1 - K~^-1 V K~^-1) = 1/2 Li^T (I - T T^T) Li        (T = L^-1 L_V)
@@ -400,11 +445,13 @@ static int fit_eval_impl(gpfit_ctx* c, void* stream, const double* theta, const 
     }
     GP_TRY(launch_add_diag(RP(c->Wbuf), ld, np, 1.0, s));
     GP_TRY(launch_symmetrize(RP(c->Wbuf), ld, np, s));
+    phase(5, s);
     {
       static const int ts_min = getenv("GPFIT_TS_MIN") ? atoi(getenv("GPFIT_TS_MIN")) : 4096;
       TwoSidedBufs<R> tb{RP(c->Wbuf), RP(c->Libuf), RP(c->Tbuf), RP(c->Zbuf), RP(c->Tmp), ld, ts_min > 0 ? ts_min : (1 << 30)};
       GP_TRY(two_sided<R>(tb, 0, np, s));
     }
+    phase(6, s);
     GP_TRY(launch_adjoint(RP(c->Tbuf), RP(c->Cos), ld, RP(c->bv), RP(c->q), n, np, RP(c->Abuf), c->upart, c->vpart, c->sumA_part, s));
     const int t64 = np / 64;
     GP_TRY(launch_adjoint_reduce(c->upart, c->vpart, c->sumA_part, t64, t64 * (t64 + 1) / 2, RP(c->q), RP(c->wl), n, np,
@@ -433,6 +480,8 @@ static int fit_eval_impl(gpfit_ctx* c, void* stream, const double* theta, const 
   if (f_out) GP_HIP(hipMemcpyAsync(f_out, RP(c->fvec), (size_t)n * sizeof(R), hipMemcpyDeviceToDevice, s));
   GP_HIP(hipMemcpyAsync(c->scal_host, c->scal, 64 * sizeof(double), hipMemcpyDeviceToHost, s));
   GP_HIP(hipMemcpyAsync(c->info_host, c->info, 4 * sizeof(int), hipMemcpyDeviceToHost, s));
+  phase(7, s);
+  c->phase_valid = (c->profile == 2 && want_grad && !reuse_V);
   c->last_enqueue_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_host0).count();
   c->pend.active = true; c->pend.stream = s; c->pend.A = A; c->pend.lambda0 = lambda0; c->pend.sigma0 = th.sigma0;
   c->pend.n = n; c->pend.np = np; c->pend.d = d; c->pend.want_grad = want_grad; c->pend.elem_bytes = (int)sizeof(R);
@@ -638,7 +687,7 @@ int gpfit_ctx_create(int device, int64_t n_max, int64_t d_max, int64_t d_full_ma
   A(&c->rect_part, t64 * t64);
   A(&c->frob_part, (np / TILE) * (np / TILE + 1) / 2); A(&c->trmv_part, (np / 512 + 1) * np);
   A(&c->scal, 64);
-  for (int i = 0; i < 2 && !rc; ++i) {
+  for (int i = 0; i < 4 && !rc; ++i) {
     double* w = nullptr;
     rc = dev_alloc(c, &w, SK_WS_BYTES / sizeof(double));
     c->sk_ws[i] = w;
@@ -660,6 +709,12 @@ int gpfit_ctx_create(int device, int64_t n_max, int64_t d_max, int64_t d_full_ma
     const char* e = getenv("GPFIT_AUX_PRIO");  // tuning knob: 0 = default priority
     if (e && atoi(e) == 0) GP_HIP(hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking));
     else GP_HIP(hipStreamCreateWithPriority(&c->aux, hipStreamNonBlocking, least));
+  }
+  {
+    // side streams of the two chains: off the critical path, lowest priority
+    int least = 0, greatest = 0;
+    GP_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+    for (int i = 0; i < 2; ++i) GP_HIP(hipStreamCreateWithPriority(&c->side[i], hipStreamNonBlocking, least));
   }
   GP_HIP(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
   GP_HIP(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
@@ -683,14 +738,36 @@ void gpfit_ctx_destroy(gpfit_ctx* c) {
   if (c->pix_host) (void)hipHostFree(c->pix_host);
   if (c->info_host) (void)hipHostFree(c->info_host);
   if (c->aux) (void)hipStreamDestroy(c->aux);
+  for (int i = 0; i < 2; ++i) {
+    if (c->side[i]) (void)hipStreamDestroy(c->side[i]);
+    for (hipEvent_t e : c->side_ev[i]) (void)hipEventDestroy(e);
+  }
   if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
   if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+  for (hipEvent_t e : c->phase_ev)
+    if (e) (void)hipEventDestroy(e);
   delete c;
 }
 
 int gpfit_set_profile(gpfit_ctx* c, int on) {
   if (!c) return -3;
-  c->profile = on ? 1 : 0;
+  c->profile = (on == 2) ? 2 : (on ? 1 : 0);
+  return 0;
+}
+
+int gpfit_get_phases(gpfit_ctx* c, double* out8) {
+  if (!c || !out8) return -3;
+  if (!c->phase_valid) {
+    set_error("gpfit_get_phases: no phase-timed evaluation (gpfit_set_profile(ctx, 2), then a synchronous gpfit_fit_eval with gradients)");
+    return -3;
+  }
+  DeviceGuard device_guard(c->device);
+  GP_HIP(hipDeviceSynchronize());
+  for (int i = 0; i < 8; ++i) {
+    float t = 0.f;
+    GP_HIP(hipEventElapsedTime(&t, c->phase_ev[0], c->phase_ev[i]));
+    out8[i] = t;
+  }
   return 0;
 }
 

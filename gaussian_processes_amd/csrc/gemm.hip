@@ -4,6 +4,9 @@
 
 #include <algorithm>
 #include <cstdlib>
+#include <mutex>
+#include <set>
+#include <utility>
 
 namespace gpfit {
 
@@ -22,7 +25,13 @@ __global__ __launch_bounds__(GEMM_THREADS, (T == 128 || NS > 2 ? 2 : 4)) void ge
   // bit 0 = walk backwards, bit 1 = column-major (dense output only).
   const int bid = (p.reverse & 1) ? (ntiles - 1 - (int)blockIdx.x) : (int)blockIdx.x;
   int ti, tj;
-  if (p.out_lower && (p.reverse & 2) && T == TILE) {
+  if (p.sched != nullptr) {
+    // XCD-aware schedule: the table says which tile this block id computes (-1: padding entry)
+    const int e = p.sched[blockIdx.x];
+    if (e < 0) return;
+    ti = e >> 16;
+    tj = e & 0xffff;
+  } else if (p.out_lower && (p.reverse & 2) && T == TILE) {
     // column-major walk of the lower triangle: the tiles of a tile column share op(B)'s panel and,
     // where the k range depends on the column only, stay at the same k (lock step in L2)
     const int nt = tiles_n;
@@ -108,20 +117,38 @@ int gemm_pick_tile(const GemmArgsT<R>& a) {
   return (a.M <= t32_dim && a.N <= t32_dim) ? 32 : 64;
 }
 
+constexpr int HALF_OCC_LDS = 17 * 1024;
+// a kernel whose static + dynamic LDS exceeds 64 KiB needs the limit raised once per (function, device)
+static void allow_dynamic_lds(const void* fn) {
+  static std::mutex mu;
+  static std::set<std::pair<const void*, int>> done;
+  int device = 0;
+  (void)hipGetDevice(&device);
+  std::lock_guard<std::mutex> lock(mu);
+  if (done.insert({fn, device}).second)
+    (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, HALF_OCC_LDS);
+}
+
 template <typename R, int T>
 static void launch_T(const GemmArgsT<R>& p, hipStream_t s) {
   const int tm = (p.M + T - 1) / T, tn = (p.N + T - 1) / T;
   const int tiles = p.out_lower ? lower_tile_count((p.M + TILE - 1) / TILE, TILE / T) : tm * tn;
   const bool edge = (p.M % T) || (p.N % T) || (p.out_lower && (p.M % TILE));
-  dim3 grid(p.tile_limit > 0 ? std::min(p.tile_limit, tiles) : tiles, p.batch, p.split_k > 1 ? p.split_k : 1);
+  dim3 grid(p.sched ? p.sched_blocks : (p.tile_limit > 0 ? std::min(p.tile_limit, tiles) : tiles), p.batch,
+            p.split_k > 1 ? p.split_k : 1);
   dim3 block(GEMM_THREADS);
   constexpr int DEEP = (T == 128) ? 2 : (T == 64 ? 4 : 8);
   static const int deep_max = getenv("GPFIT_DEEP_MAX") ? atoi(getenv("GPFIT_DEEP_MAX")) : 512;  // tuning knob
   const bool deep = DEEP > 2 && !edge && (long)grid.x * grid.y * grid.z <= deep_max;
+  // half-occupancy launches (T = 128 only): 64 KiB static + 17 KiB of unused dynamic LDS = 81 KiB > 160 / 2
+  const bool half = (T == TILE) && p.half_occ && !deep;
 #define GP_LAUNCH(AK, BK, ED)                                                                          \
   do {                                                                                                 \
     if (deep) hipLaunchKernelGGL((gemm_mfma_kernel<R, AK, BK, ED, T, (ED ? 2 : DEEP)>), grid, block, 0, s, p, tn, tiles); \
-    else hipLaunchKernelGGL((gemm_mfma_kernel<R, AK, BK, ED, T, 2>), grid, block, 0, s, p, tn, tiles); \
+    else if (half) {                                                                                   \
+      allow_dynamic_lds(reinterpret_cast<const void*>(gemm_mfma_kernel<R, AK, BK, ED, T, 2>));          \
+      hipLaunchKernelGGL((gemm_mfma_kernel<R, AK, BK, ED, T, 2>), grid, block, HALF_OCC_LDS, s, p, tn, tiles); \
+    } else hipLaunchKernelGGL((gemm_mfma_kernel<R, AK, BK, ED, T, 2>), grid, block, 0, s, p, tn, tiles); \
   } while (0)
   const int sel = (p.a_kmajor ? 4 : 0) | (p.b_kmajor ? 2 : 0) | (edge ? 1 : 0);
   switch (sel) {
@@ -141,6 +168,10 @@ template <typename R>
 int launch_gemm(const GemmArgsT<R>& a, hipStream_t s) {
   if (a.M <= 0 || a.N <= 0) return 0;
   if (a.tile_limit == 0 && gemm_pick_tile(a) == TILE && a.batch <= 1) {
+    if (a.reverse & 8) {
+      const int rc = launch_gemm_xcd(a, s);    // XCD-aware data-parallel schedule (gemm_sched.hip)
+      if (rc <= 0) return rc;
+    }
     const int rc = launch_gemm_streamk(a, s);  // large launches: balanced schedules (gemm_streamk.hip)
     if (rc <= 0) return rc;
   }

@@ -15,6 +15,11 @@ template <typename R>
 int launch_chol_leaf(const R* A, int64_t lda, R* L, int64_t ldl, R* Linv, int64_t ldi, int* info, int info_base,
                      hipStream_t s);
 
+// ---- chol_leaf_reg.hip: same contract, matrix in registers, 21 KiB of LDS (co-resident with GEMM workgroups)
+template <typename R>
+int launch_chol_leaf_reg(const R* A, int64_t lda, R* L, int64_t ldl, R* Linv, int64_t ldi, int* info, int info_base,
+                         hipStream_t s);
+
 // ---- elementwise.hip  (templated on the scalar type R = double | float; reductions are always
 //      accumulated and returned in fp64)
 // Spatial metric C (utils.py:861-914) over the masked pixels pix[d] of an n_rows x n_cols

@@ -69,8 +69,16 @@ class GPFitEngine:
             t = t.contiguous()
         return t
 
-    def set_profile(self, on: bool):
-        _lib.check(self.lib.gpfit_set_profile(self._ctx, 1 if on else 0), "gpfit_set_profile")
+    def set_profile(self, on):
+        """0 / False off, 1 / True per-launch events of the dominant kernels, 2 phase timing only."""
+        _lib.check(self.lib.gpfit_set_profile(self._ctx, int(on)), "gpfit_set_profile")
+
+    def get_phases(self):
+        """Milliseconds from the start of the last phase-timed evaluation to each phase boundary."""
+        out = (ctypes.c_double * 8)()
+        _lib.check(self.lib.gpfit_get_phases(self._ctx, out), "gpfit_get_phases")
+        names = ("start", "kernel_build_done", "chol_K_done", "chol_V_done", "T_done", "Q_done", "W_done", "end")
+        return {k: round(out[i], 4) for i, k in enumerate(names)}
 
     def get_profile(self):
         out = (ctypes.c_double * 16)()

@@ -192,6 +192,13 @@ int gpfit_nd_utility(void* stream, const double* sigma2, const double* mu, int64
  *        GEMM launch (L^-1 L_V at the headline), 13-15 unused. */
 int gpfit_set_profile(gpfit_ctx* ctx, int on);
 int gpfit_get_profile(gpfit_ctx* ctx, double* out16);
+/* Phase timing (gpfit_set_profile(ctx, 2)): eight HIP events per evaluation and none inside the
+ * factorisations, so the timed run is the production schedule.  out8[i] = milliseconds from the start
+ * of the last synchronous gpfit_fit_eval (with gradients) to: 0 start, 1 kernel build + moments done
+ * (the two factorisation chains start here), 2 Cholesky + inverse of K~ done (main stream), 3 Cholesky
+ * of V done (auxiliary stream), 4 T = L^-1 L_V and its norm done, 5 Q = I - T T^T done, 6 two-sided
+ * product W done, 7 end (gradient contraction, scalars copied). */
+int gpfit_get_phases(gpfit_ctx* ctx, double* out8);
 /* Host milliseconds the last gpfit_fit_eval spent enqueuing work (before its final sync). */
 double gpfit_last_enqueue_ms(gpfit_ctx* ctx);
 

@@ -1,0 +1,34 @@
+// Phase timing inside the register-resident leaf (dev tool):
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -Iinclude -Igaussian_processes_amd/csrc scripts/dev_leaf_time.hip -o /tmp/leaf_time && /tmp/leaf_time
+#define GPFIT_LEAF_STAMPS 1
+#include "../gaussian_processes_amd/csrc/chol_leaf_reg.hip"
+#include <vector>
+#include <cstdio>
+#include <cmath>
+namespace gpfit { void set_error(const std::string&) {} }
+int main() {
+  const int n = 128;
+  std::vector<double> A(n * n);
+  for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) A[i * n + j] = (i == j ? n : 0.0) + std::cos(0.37 * (i + 1) * (j + 1)) * 0.5 + std::cos(0.37 * (j + 1) * (i + 1)) * 0.5;
+  double *dA, *dL, *dI; int* info;
+  hipMalloc(&dA, n * n * 8); hipMalloc(&dL, n * n * 8); hipMalloc(&dI, n * n * 8); hipMalloc(&info, 16);
+  hipMemcpy(dA, A.data(), n * n * 8, hipMemcpyHostToDevice); hipMemset(info, 0, 16);
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  for (int it = 0; it < 3; ++it) gpfit::launch_chol_leaf_reg<double>(dA, n, dL, n, dI, n, info, 0, 0);
+  hipEventRecord(e0, 0);
+  for (int it = 0; it < 100; ++it) gpfit::launch_chol_leaf_reg<double>(dA, n, dL, n, dI, n, info, 0, 0);
+  hipEventRecord(e1, 0); hipDeviceSynchronize();
+  float ms; hipEventElapsedTime(&ms, e0, e1);
+  printf("back-to-back leaf launches: %.2f us each\n", ms * 10.0);
+  long long st[72];
+  hipMemcpyFromSymbol(st, HIP_SYMBOL(gpfit::g_leaf_stamps), sizeof(st));
+  const double t0 = (double)st[64];
+  printf("panels start at 0, kernel end %.0f cycles\n", (double)st[65] - t0);
+  const char* names[7] = {"start", "rows-read", "pivots+inv", "written", "barrier1", "solve+b2", "updates+b3"};
+  for (int kb = 0; kb < 8; ++kb) {
+    printf("panel %d:", kb);
+    for (int ph = 0; ph < 7; ++ph) printf(" %s %.0f", names[ph], (double)st[kb * 8 + ph] - t0);
+    printf("\n");
+  }
+  return 0;
+}
