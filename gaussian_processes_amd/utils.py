@@ -291,7 +291,15 @@ def is_posdef(tensor, name='M'):
     if not is_simmetric(tensor, name=name):
         warnings.warn('The matrix is not symmetric, cannot check if it is positive definite')
         return False
-    smallest = float(torch.linalg.eigvalsh(_cu(tensor)).min())
+    # cheap proof first: a successful Cholesky with 1 / (||L^-1||_1 ||L^-1||_inf) > MIN_TOLERANCE bounds the
+    # smallest eigenvalue from below (see _all_eigenvalues_kept); eigvalsh only when that is inconclusive
+    t = _cu(tensor)
+    L, Li, _, info = cholesky(t, want_inverse=True)
+    if info == 0:
+        ali = Li.abs()
+        if 1.0 / (float(ali.sum(0).max()) * float(ali.sum(1).max())) > MIN_TOLERANCE:
+            return True
+    smallest = float(torch.linalg.eigvalsh(t).min())
     if smallest <= 0.:
         warnings.warn(f'Matrix {name} is simmetric but has an eigenvalue smaller than 0 ')
         return False
@@ -493,7 +501,8 @@ def lambda_moments_star(xstar, xtilde, C, theta, K_tilde, K_tilde_inv, m, V, B, 
     elif not callable(kernfun):
         raise Exception('Kernel function not recognized')
     Kvec_star = kernfun(theta, xstar, xtilde, C=C, dC=None, diag=False)          # :1486
-    Kvec_star = matmul(Kvec_star, B)                                              # :1487
+    if not _is_identity(B):
+        Kvec_star = matmul(Kvec_star, B)                                          # :1487
     a = matmul(Kvec_star, K_tilde_inv)                                            # :1489
     mu_star = matmul(a, m)                                                        # :1491
     K_star = kernfun(theta, xstar, x2=None, C=C, dC=None, diag=True)              # :1494
@@ -636,6 +645,65 @@ def _eigen_stabilise(K_tilde):
     eigvals, eigvecs = torch.linalg.eigh(K_tilde, UPLO='L')
     ikeep = eigvals > max(float(eigvals.max()) * EIGVAL_TOL, EIGVAL_TOL)
     return eigvals, eigvecs, ikeep
+
+
+def _mark_identity(B):
+    B._gpfit_identity = True       # fast-path hint only: products with B are skipped where it is seen
+    return B
+
+
+def _is_identity(B):
+    return bool(getattr(B, '_gpfit_identity', False))
+
+
+def _all_eigenvalues_kept(K_tilde):
+    """Rank decision without an eigendecomposition, for the regime the reference's
+    truncation rule (utils.py:1683, 1809) keeps EVERY eigenvalue: lambda_min > max(lambda_max tol, tol).
+
+    From the Cholesky factorisation the fit needs anyway (K~ = L L^T, L^-1 by the MFMA recursion):
+        lambda_max <= min(trace K~, ||K~||_inf)                 (SPD; Gershgorin)
+        lambda_min  = 1 / ||L^-T L^-1||_2 >= 1 / (||L^-1||_1 ||L^-1||_inf)
+    Both bounds are rigorous, so ``True`` is a proof that nothing would be truncated; when they are
+    inconclusive (or K~ is not numerically positive definite) the caller falls back to
+    ``torch.linalg.eigh``.  Returns ``(decided_all_kept, L, Linv)``."""
+    n = K_tilde.shape[0]
+    L, Li, _, info = cholesky(K_tilde, want_inverse=True)
+    if info != 0:
+        return False, None, None
+    lam_max_ub = min(float(torch.diagonal(K_tilde).sum()), float(K_tilde.abs().sum(1).max()))
+    ali = Li.abs()
+    lam_min_lb = 1.0 / (float(ali.sum(0).max()) * float(ali.sum(1).max()))
+    del ali
+    if not (math.isfinite(lam_max_ub) and math.isfinite(lam_min_lb)):
+        return False, None, None
+    return lam_min_lb > max(lam_max_ub * EIGVAL_TOL, EIGVAL_TOL), L, Li
+
+
+def _stabilised_basis(K_tilde):
+    """Basis the reference works in after its eigen-stabilisation (utils.py:1682-1694): returns
+    ``(eigvecs, B, K_tilde_b, K_tilde_inv_b)``.
+
+    When every eigenvalue is provably kept (``_all_eigenvalues_kept``) B is square orthogonal and
+    everything the reference computes downstream is basis-invariant, so the
+    identity is used: ``B = I``, ``K_tilde_b = K~``, ``K_tilde_inv_b = L^-T L^-1`` -- no ``eigh``
+    (0.67 s at N = 8192, five of them in a four-iteration fit).  Otherwise the reference's own
+    eigendecomposition + truncation.  Deterministic in K~, so ``test(at_iteration=...)`` rebuilds
+    the basis the tracked ``(m_b, V_b)`` were expressed in."""
+    n = K_tilde.shape[0]
+    if not _FORCE_EIGH:
+        kept, L, Li = _all_eigenvalues_kept(K_tilde)
+        if kept:
+            B = _mark_identity(torch.eye(n, dtype=TORCH_DTYPE, device=K_tilde.device))
+            Kinv = matmul(Li, Li, transA=True)
+            return None, B, K_tilde, (Kinv + Kinv.T) * 0.5
+    eigvals, eigvecs, ikeep = _eigen_stabilise(K_tilde)
+    B = eigvecs[:, ikeep].contiguous()
+    kept = eigvals[ikeep]
+    return eigvecs, B, torch.diag(kept), torch.diag_embed(1 / kept)
+
+
+import os as _os_mod
+_FORCE_EIGH = bool(_os_mod.environ.get("GPFIT_FORCE_EIGH"))   # tuning / A-B knob: always take the eigh route
 
 
 def _closure_general(theta, lims, n_px_side, x, xtilde, r, B, m_b, V_b, f_params, ntilde, nt):
@@ -868,14 +936,30 @@ def varGP(x, r, **kwargs):
         return C_, mask_, Kt, K_, Kv, x_m
 
     def project(Kt, K_):
-        eigvals_, eigvecs_, ikeep_ = _eigen_stabilise(Kt)
-        B_ = eigvecs_[:, ikeep_].contiguous()
-        kept = eigvals_[ikeep_]
-        Ktb = torch.diag(kept)
-        Ktib = torch.diag_embed(1 / kept)
-        Kb = matmul(K_, B_)
-        a_ = matmul(Kb, Ktib) if ntilde != nt else B_
+        eigvecs_, B_, Ktb, Ktib = _stabilised_basis(Kt)
+        if _is_identity(B_):
+            Kb = K_
+            a_ = matmul(Kb, Ktib) if ntilde != nt else B_
+        else:
+            Kb = matmul(K_, B_)
+            a_ = matmul(Kb, Ktib) if ntilde != nt else B_
         return eigvecs_, B_, Ktb, Ktib, Kb, a_
+
+    def to_basis_vec(B_, v):
+        return v.clone() if _is_identity(B_) else matmul(B_, v, transA=True)
+
+    def to_basis_mat(B_, M):
+        if _is_identity(B_):
+            return M.clone()
+        Mb = matmul(B_, matmul(M, B_), transA=True)
+        return Mb
+
+    def moments_now():
+        """lambda moments of the current state (utils.py:1090, 1101); with a = B = I they reduce to
+        lambda_m = m, lambda_var = Kvec - diag(K~) + diag(V) and no N^3 product is formed."""
+        if _is_identity(B) and ntilde == nt:
+            return m_b.clone(), Kvec - torch.diagonal(K_tilde_b) + torch.diagonal(V_b)
+        return lambda_moments(x_m, K_tilde_b, KKtilde_inv_b, Kvec, K_b, C, m_b, V_b, theta, kernfun=kernfun)
 
     if 'init_kernel' not in kwargs:
         C, mask, K_tilde, K, Kvec, x_m = build_kernels(theta)
@@ -889,8 +973,8 @@ def varGP(x, r, **kwargs):
 
     m = _cu(copy.deepcopy(kwargs.get('m', torch.zeros(ntilde, dtype=TORCH_DTYPE))).detach())
     V = _cu(copy.deepcopy(kwargs.get('V', K_tilde)).detach())
-    V_b = matmul(B, matmul(V, B), transA=True) if 'V' in kwargs else K_tilde_b
-    m_b = matmul(B, m, transA=True)
+    V_b = to_basis_mat(B, V) if 'V' in kwargs else K_tilde_b
+    m_b = to_basis_vec(B, m)
 
     import os as _os
     no_fast = bool(_os.environ.get("GPFIT_NO_FAST"))
@@ -898,7 +982,7 @@ def varGP(x, r, **kwargs):
     def full_rank():
         return (not no_fast) and same_points and B.shape[0] == B.shape[1]
 
-    lambda_m, lambda_var = lambda_moments(x_m, K_tilde_b, KKtilde_inv_b, Kvec, K_b, C, m_b, V_b, theta, kernfun=kernfun)
+    lambda_m, lambda_var = moments_now()
     f_mean = mean_f_given_lambda_moments(f_params, lambda_m, lambda_var)
     loglikelihood, _, __ = compute_loglikelihood(r, f_mean, lambda_m, lambda_var, f_params)
     KL_div = compute_KL_div(m_b, V_b, K_tilde_b, K_tilde_inv_b, dK_tilde=None, ignore_warning=True)
@@ -935,22 +1019,25 @@ def varGP(x, r, **kwargs):
                 C, mask, K_tilde, K, Kvec, x_m = build_kernels(theta)                       # utils.py:1803-1806
                 B_old = B
                 eigvecs, B, K_tilde_b, K_tilde_inv_b, K_b, KKtilde_inv_b = project(K_tilde, K)   # :1808-1818
-                BtB = matmul(B, B_old, transA=True)
-                V_b = matmul(BtB, matmul(V_b, BtB, transB=True))                           # :1833
-                m_b = matmul(BtB, m_b)                                                     # :1840
+                if _is_identity(B) and _is_identity(B_old):
+                    pass                                      # B^T B_old = I: (m_b, V_b) unchanged
+                else:
+                    BtB = B_old if _is_identity(B) else (B.T.contiguous() if _is_identity(B_old)
+                                                           else matmul(B, B_old, transA=True))
+                    V_b = matmul(BtB, matmul(V_b, BtB, transB=True))                       # :1833
+                    m_b = matmul(BtB, m_b)                                                 # :1840
             times['kernels'] += time.time() - t0
 
             t0 = time.time()
             if nEstep > 0:
                 for i_estep in range(nEstep):
                     if i_estep == 0 and nMstep > 0:
-                        lambda_m, lambda_var = lambda_moments(x_m, K_tilde_b, KKtilde_inv_b, Kvec, K_b, C, m_b, V_b,
-                                                              theta, kernfun=kernfun)         # :1871
+                        lambda_m, lambda_var = moments_now()                                  # :1871
                         f_params['lambda0'] = lambda0_given_logA(f_params['logA'], r, lambda_m, lambda_var)  # :1874
                     f_mean = mean_f_given_lambda_moments(f_params, lambda_m, lambda_var)        # :1877
                     if full_rank():
                         # fused Newton update in the original basis, then back to the eigenbasis
-                        m_orig = matmul(B, m_b)
+                        m_orig = m_b if _is_identity(B) else matmul(B, m_b)
                         m_new = torch.empty(nt, dtype=TORCH_DTYPE, device=dev)
                         V_new = torch.empty((nt, nt), dtype=TORCH_DTYPE, device=dev)
                         eng = get_engine(nt, 1)
@@ -966,15 +1053,17 @@ def varGP(x, r, **kwargs):
                                                  f'called 1 times in estep {i_estep} iteration. Try substituting '
                                                  f'them with inf.')
                             raise torch.linalg.LinAlgError(f"Estep: {_lib.last_error()} (rc={rc})")
-                        m_b = matmul(B, m_new, transA=True)
-                        V_b = matmul(B, matmul(V_new, B), transA=True)
-                        V_b = (V_b + V_b.T) / 2
+                        if _is_identity(B):
+                            m_b, V_b = m_new, V_new            # symmetric by construction (gpfit_estep)
+                        else:
+                            m_b = matmul(B, m_new, transA=True)
+                            V_b = matmul(B, matmul(V_new, B), transA=True)
+                            V_b = (V_b + V_b.T) / 2
                     else:
                         m_b, V_b = Estep(r=r, KKtilde_inv=KKtilde_inv_b, m=m_b, f_params=f_params, f_mean=f_mean,
                                          K_tilde=K_tilde_b, K_tilde_inv=K_tilde_inv_b, update_V_inv=False, alpha=1)  # :1880
-                    f_mean, lambda_m, lambda_var = mean_f(f_params=f_params, calculate_moments=True, x=x_m,
-                                                          K_tilde=K_tilde_b, KKtilde_inv=KKtilde_inv_b, Kvec=Kvec, K=K_b,
-                                                          C=C, m=m_b, V=V_b, theta=theta, kernfun=kernfun)   # :1884
+                    lambda_m, lambda_var = moments_now()                                        # :1884
+                    f_mean = mean_f_given_lambda_moments(f_params, lambda_m, lambda_var)
                     tf = time.time()
                     f_params['lambda0'] = lambda0_given_logA(f_params['logA'], r, lambda_m, lambda_var)      # :1892
                     opt_f = torch.optim.LBFGS([f_params['logA']], lr=0.1, max_iter=nFparamstep, tolerance_change=1.e-9,
@@ -1018,9 +1107,12 @@ def varGP(x, r, **kwargs):
                 fast = full_rank()
                 if fast:
                     # (m, V) are fixed during the M-step: go to the original basis once
-                    m_orig = matmul(B, m_b)
-                    V_orig = matmul(B, matmul(V_b, B, transB=True))
-                    V_orig = (V_orig + V_orig.T) * 0.5
+                    if _is_identity(B):
+                        m_orig, V_orig = m_b, V_b
+                    else:
+                        m_orig = matmul(B, m_b)
+                        V_orig = matmul(B, matmul(V_b, B, transB=True))
+                        V_orig = (V_orig + V_orig.T) * 0.5
                 mcalls = [0]
                 v_factored = [False]
 
@@ -1081,9 +1173,8 @@ def varGP(x, r, **kwargs):
         # utils.py:2194-2231 (the `finally` block when is_error): kernels at the theta in force, final loss
         C, mask, K_tilde, K, Kvec, x_m = build_kernels(theta)
         eigvecs, B, K_tilde_b, K_tilde_inv_b, K_b, KKtilde_inv_b = project(K_tilde, K)
-        f_mean, lambda_m, lambda_var = mean_f(f_params=f_params, calculate_moments=True, x=x_m, K_tilde=K_tilde_b,
-                                              KKtilde_inv=KKtilde_inv_b, Kvec=Kvec, K=K_b, C=C, m=m_b, V=V_b,
-                                              theta=theta, kernfun=kernfun)
+        lambda_m, lambda_var = moments_now()
+        f_mean = mean_f_given_lambda_moments(f_params, lambda_m, lambda_var)
         loglikelihood = compute_loglikelihood(r, f_mean, lambda_m, lambda_var, f_params)[0]
         KL_div = compute_KL_div(m_b, V_b, K_tilde_b, K_tilde_inv_b, dK_tilde=None)
         logmarginal = loglikelihood - KL_div
@@ -1155,10 +1246,7 @@ def test(X_test, R_test, xtilde, X_train=None, at_iteration=None, **kwargs):
                            n_px_side=n_px_side, grad=False)
         xt_m = xtilde[:, mask].contiguous()
         Kt = acosker(theta, xt_m, xt_m, C=C, diag=False)
-        eigvals, eigvecs, ikeep = _eigen_stabilise(Kt)
-        B = eigvecs[:, ikeep].contiguous()
-        K_tilde = torch.diag(eigvals[ikeep])
-        K_tilde_inv = torch.diag_embed(1 / eigvals[ikeep])
+        _, B, K_tilde, K_tilde_inv = _stabilised_basis(Kt)
 
     X_test = _cu(X_test)
     n_img = X_test.shape[0]

@@ -514,6 +514,56 @@ def test_pending_evaluation_blocks_other_entry_points():
     eng.close()
 
 
+def test_rank_decision_without_eigh(gp):
+    """SURVEY 8 f-1 (second half): the reference's truncation rule (utils.py:1683) decided from the
+    Cholesky factor instead of an eigendecomposition.  (a) well-conditioned K~ with a tiny tolerance:
+    rigorous bounds prove that every eigenvalue is kept -> B = I, K~_b = K~, K~_b^-1 = L^-T L^-1;
+    (b) the same matrix at the reference's default tolerance, where eigh truncates: the bounds must
+    NOT claim full rank; (c) the claim is never wrong: whenever the shortcut says 'all kept', eigh
+    agrees; (d) a fit through the identity basis and one forced through eigh give the same
+    basis-invariant results."""
+    th = tth(syn.theta0()[k] for k in KEYS) if False else tth([syn.theta0()[k] for k in KEYS])
+    C, mask = gp.localker(th, UPPER, LOWER, 8)
+    old = gp.EIGVAL_TOL
+    try:
+        for N in (96, 300, 700):
+            X = T(syn.stimuli(N, 64))[:, mask].contiguous()
+            Kt = gp.acosker(th, X, X, C=C)
+            ev = torch.linalg.eigvalsh(Kt)
+            for tol in (1e-14, 1e-9, 1e-6, 1e-4, 1e-2):
+                gp.EIGVAL_TOL = tol
+                truth = bool((ev > max(float(ev.max()) * tol, tol)).all())
+                kept, L, Li = gp._all_eigenvalues_kept(Kt)
+                assert (not kept) or truth, (N, tol)            # (c) never a false claim
+                if tol == 1e-14:
+                    assert kept and truth                        # (a)
+                    _, B, Ktb, Ktib = gp._stabilised_basis(Kt)
+                    assert gp._is_identity(B) and torch.equal(Ktb, Kt)
+                    assert relerr((Ktib @ Kt).cpu().numpy(), np.eye(N)) < 1e-9
+            gp.EIGVAL_TOL = 1e-4
+            _, B, Ktb, _ = gp._stabilised_basis(Kt)
+            n_kept = int((ev > max(float(ev.max()) * 1e-4, 1e-4)).sum())
+            assert B.shape[1] == n_kept                          # (b) default tolerance: the reference's own count
+    finally:
+        gp.EIGVAL_TOL = old
+    # (d) whole fit, identity basis vs forced eigh
+    g = load_golden("g6_vargp_full_N128.npz")
+    fit_a, err_a, R_a = _run_vargp(gp, g)
+    assert gp._is_identity(fit_a["B"]) and fit_a["final_kernel"]["eigvecs"] is None
+    gp._FORCE_EIGH = True
+    try:
+        fit_b, err_b, R_b = _run_vargp(gp, g)
+    finally:
+        gp._FORCE_EIGH = False
+    assert not gp._is_identity(fit_b["B"]) and fit_b["final_kernel"]["eigvecs"] is not None
+    la, lb = (f["values_track"]["loss_track"]["logmarginal"].numpy() for f in (fit_a, fit_b))
+    assert relerr(la, lb) < 1e-8 and relerr(la, g["logmarginal"]) < 1e-6
+    assert relerr(R_a.cpu().numpy(), R_b.cpu().numpy()) < 1e-7
+    Bb = fit_b["B"]
+    assert relerr(fit_a["m_b"].cpu().numpy(), gp.matmul(Bb, fit_b["m_b"]).cpu().numpy()) < 1e-6
+    assert relerr(fit_a["V_b"].cpu().numpy(), gp.matmul(Bb, gp.matmul(fit_b["V_b"], Bb, transB=True)).cpu().numpy()) < 1e-6
+
+
 def test_nd_utility_matches_reference(gp):
     """Active-learning utility: device kernel incl. Lambert W against the real
     reference's nd_utility (scipy Lambert W) on the G8 fixture -- values from 7e-8 to 6e7, entries
