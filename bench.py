@@ -1,20 +1,28 @@
-"""Headline benchmark: GP fits/sec at N=8192, d=256, fp64 (BASELINE.json configs[2]).
+"""Benchmark of the GP fit hot path on MI355X (BASELINE.json): GP fits/sec at N=8192, d=256, fp64.
 
-One "step" = one evaluation of the unit of work: spatial metric +
-arc-cosine kernel build + Cholesky(K~) + Cholesky(V) + solves + log-marginal + 6 analytic
-gradients + lambda moments, on inputs already resident in HBM.
+One "step" = one pass of the hot path over one batch of synthetic input, inputs already resident
+in HBM.  The unit of work is one evaluation of the M-step closure:
+spatial metric + arc-cosine kernel build + Cholesky(K~) + Cholesky(V) + solves + log-marginal + six
+analytic gradients.
 
-    python bench.py --gpus 1 --steps 10 --warmup 2
+    python bench.py --gpus 1 --steps 10 --warmup 2                     # headline (BASELINE configs[2])
+    python bench.py --config n4096                                      # configs[1]: N=4096, d=128
+    python bench.py --config cells64                                    # configs[3]: 64 cells x N=4096, sharded
+    python bench.py --config thetagrid                                  # configs[4]: 512 theta x N=8192, fp32
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-        --master-port P bench.py --gpus N --steps K --warmup W
+        --master-port P bench.py --gpus N --steps K --warmup W [--config ...]
 
-N > 1: one process per GPU, each rank evaluates its own cell (weak scaling); the shared
-stimulus matrix X is generated on rank 0 and broadcast over RCCL once, outside the timed
-region; there is no collective on the data path.  Rank 0 prints ONE JSON line.
+N > 1: one process per GPU over RCCL.  headline / n4096: every rank evaluates its own cell (weak
+scaling); cells64 / thetagrid: the 64 cells / 512 theta points are sharded cyclically over the ranks
+(strong scaling: one step = one pass over all units).  The shared stimulus matrix X is generated on
+rank 0 and broadcast once outside the timed region (thetagrid also broadcasts r, m, V:
+multi.broadcast_state); there is no collective on the data path.  Rank 0 prints ONE JSON line.
 """
 from __future__ import annotations
 
 import argparse
+import csv
+import glob
 import json
 import math
 import os
@@ -27,7 +35,7 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from gaussian_processes_amd import synthetic as syn  # noqa: E402
+from gaussian_processes_amd import multi, synthetic as syn  # noqa: E402
 from gaussian_processes_amd.engine import GPFitEngine, fits_flops  # noqa: E402
 
 FP64_MFMA_PEAK_TFLOPS = 78.6  # MI355X dense fp64 matrix peak (AMD datasheet; rocBLAS dgemm reaches 76.7 on-box)
@@ -55,28 +63,45 @@ def host_cores() -> int:
     return max(1, min(n, 32))
 
 
-def profiled_traffic(kernel_name):
-    """HBM bytes per launch of the named kernel, from the committed PMC passes
+def latest_profile(pattern):
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)))
+    return files[-1] if files else None
+
+
+def profiled_traffic(kernel_name, blocks=None):
+    """HBM-side bytes per launch of the named kernel, from the committed PMC passes
     (profiles/r*_summary.json: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE of this same
     command, FETCH_SIZE doubled per the gfx950 correction).  PMC collection needs its own
     profiler runs, so this is read from the tracked profile, not measured live; None if absent."""
-    import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_summary.json")))
-    if not files:
+    f = latest_profile("r*_summary.json")
+    if not f:
         return None
     try:
-        rows = json.load(open(files[-1])).get("hbm_traffic_by_kernel") or []
-        if not rows:
-            return None
-        match = [x for x in rows if kernel_name in x["kernel"]]
+        rows = json.load(open(f)).get("hbm_traffic_by_kernel") or []
+        match = [x for x in rows if kernel_name in x["kernel"] and (blocks is None or x["blocks"] == blocks)]
         if not match:
             return None
         r = max(match, key=lambda x: x["fetch_corrected_GB_per_launch"])
         return {"unit": "GB/launch", "kernel": r["kernel"], "blocks": r["blocks"],
                 "fetch_corrected": round(r["fetch_corrected_GB_per_launch"], 3),
-                "write": round(r["write_GB_per_launch"], 3), "source": os.path.basename(files[-1])}
+                "write": round(r["write_GB_per_launch"], 3), "source": os.path.basename(f)}
     except Exception:
         return None
+
+
+def profiled_mfma_util(kernel_name):
+    """Matrix-pipe utilisation of the named kernel from the committed PMC pass
+    (profiles/r*_mfma_busy.csv: SQ_VALU_MFMA_BUSY_CYCLES / GRBM_GUI_ACTIVE / 128); None if absent."""
+    f = latest_profile("r*_mfma_busy.csv")
+    if not f:
+        return None
+    try:
+        for r in csv.reader(open(f)):
+            if r and kernel_name in r[0]:
+                return {"mfma_pipe_utilisation": float(r[5]), "dispatches": int(r[1]), "source": os.path.basename(f)}
+    except Exception:
+        pass
+    return None
 
 
 def build_V(X, grid, th0, dev):
@@ -91,18 +116,15 @@ def build_V(X, grid, th0, dev):
     return 0.5 * K
 
 
-def cpu_baseline(n_sample: int, d: int, budget_s: float = 30.0):
+def cpu_reference_eval(n, d, repeats, do_cholesky=True):
     """Reference-formulation closure (oracle.mstep_closure_reference: materialised dK{6},
-    eigen-projection, LU inverse, 13+13 GEMM gradient products; torch CPU fp64) timed on the
-    host cores of this box on a bounded sample, plus the CPU Cholesky restatement."""
+    eigen-projection, LU inverse, 13+13 GEMM gradient products; torch CPU fp64) on the host cores of
+    this box: one warm-up + `repeats` timed evaluations; optionally the CPU Cholesky restatement."""
     from oracle import gp_oracle as orc
-    cores = host_cores()
-    torch.set_num_threads(cores)
-    log(f"cpu_baseline: {cores} threads, sample N={n_sample}")
     lower, upper = syn.limits()
     grid = syn.grid_for(d)
-    X = torch.from_numpy(syn.stimuli(n_sample, d))
-    r_np, m_np = syn.cell_inputs(n_sample)
+    X = torch.from_numpy(syn.stimuli(n, d))
+    r_np, m_np = syn.cell_inputs(n)
     r, m = torch.from_numpy(r_np), torch.from_numpy(m_np)
     th0, th1 = syn.theta0(), syn.theta_eval()
     C0, mask0 = orc.spatial_metric(th0, lower, upper, grid)
@@ -111,23 +133,33 @@ def cpu_baseline(n_sample: int, d: int, budget_s: float = 30.0):
     ev, evec, keep = orc.eigen_basis(K0, 1e-14)  # full-rank family
     B = evec[:, keep]
     m_b, V_b = B.T @ m, B.T @ V @ B
+    del K0, ev, evec
     logA, lam0 = syn.F_PARAMS["logA"], syn.F_PARAMS["lambda0"]
-    t0 = time.time()
-    loss_ref, _ = orc.mstep_closure_reference(th1, lower, upper, grid, X, X, r, B, m_b, V_b, logA, lam0, tol=1e-14)
-    t_first = time.time() - t0
-    log(f"cpu_baseline: first reference-formulation eval {t_first:.2f}s")
-    reps, times = 0, [t_first]
-    while sum(times) + t_first < budget_s and reps < 2:
+    times = []
+    for it in range(repeats + (1 if repeats > 1 else 0)):
         t0 = time.time()
-        orc.mstep_closure_reference(th1, lower, upper, grid, X, X, r, B, m_b, V_b, logA, lam0, tol=1e-14)
+        loss_ref, _ = orc.mstep_closure_reference(th1, lower, upper, grid, X, X, r, B, m_b, V_b, logA, lam0, tol=1e-14)
         times.append(time.time() - t0)
-        reps += 1
-    t_ref = min(times)
-    t0 = time.time()
-    loss_chol, _ = orc.mstep_closure_cholesky(th1, lower, upper, grid, X, r, m, V, logA, lam0)
-    t_chol = time.time() - t0
-    return dict(t_ref=t_ref, t_chol=t_chol, cores=cores, n=n_sample, loss_ref=loss_ref, loss_chol=loss_chol,
-                repeats=len(times))
+        log(f"cpu_baseline: N={n} reference-formulation eval {it}: {times[-1]:.2f} s")
+    timed = times[1:] if repeats > 1 else times
+    out = {"n": n, "t_ref": float(np.median(timed)), "t_ref_all": [round(t, 3) for t in timed], "loss_ref": loss_ref}
+    if do_cholesky:
+        t0 = time.time()
+        loss_chol, _ = orc.mstep_closure_cholesky(th1, lower, upper, grid, X, r, m, V, logA, lam0)
+        out["t_chol"] = time.time() - t0
+        out["loss_chol"] = loss_chol
+    return out
+
+
+def cpu_baseline(n_full, d, n_sample, quick):
+    cores = host_cores()
+    torch.set_num_threads(cores)
+    log(f"cpu_baseline: {cores} threads")
+    small = cpu_reference_eval(n_sample, d, repeats=3)
+    full = None
+    if not quick and n_full > n_sample:
+        full = cpu_reference_eval(n_full, d, repeats=1)
+    return cores, small, full
 
 
 def main():
@@ -135,14 +167,21 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--n", type=int, default=8192)
-    ap.add_argument("--d", type=int, default=256)
+    ap.add_argument("--config", choices=["headline", "n4096", "cells64", "thetagrid"], default="headline",
+                    help="BASELINE.json configs[2] (default), [1], [3], [4]")
+    ap.add_argument("--n", type=int, default=0, help="override N (headline / n4096 only)")
+    ap.add_argument("--d", type=int, default=0, help="override d")
+    ap.add_argument("--cells", type=int, default=64)
+    ap.add_argument("--grid-points", type=int, default=512)
+    ap.add_argument("--depth", type=int, default=4, help="independent units kept in flight per GPU (cells64)")
     ap.add_argument("--cpu-sample-n", type=int, default=4096)
+    ap.add_argument("--cpu-quick", action="store_true", help="skip the real N=8192 CPU evaluation (about 90 s)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-grad", action="store_true", help="forward-only unit (not the headline metric)")
-    ap.add_argument("--dtype", choices=["f64", "f32"], default="f64",
-                    help="f64 = the reference's precision (headline); f32 = the theta-grid configuration's precision")
+    ap.add_argument("--dtype", choices=["f64", "f32"], default=None,
+                    help="f64 = the reference's precision; f32 = the theta-grid configuration's precision")
     args = ap.parse_args()
+    dtype_name = args.dtype or ("f32" if args.config == "thetagrid" else "f64")
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -157,50 +196,102 @@ def main():
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
 
-    N, d = args.n, args.d
+    defaults = {"headline": (8192, 256), "n4096": (4096, 128), "cells64": (4096, 128), "thetagrid": (8192, 256)}
+    N, d = defaults[args.config]
+    N, d = args.n or N, args.d or d
     grid = syn.grid_for(d)
     lower, upper = syn.limits()
-
-    # shared stimuli: generated on rank 0, broadcast over RCCL/xGMI (16 MiB at the headline)
-    if rank == 0:
-        X = torch.from_numpy(syn.stimuli(N, d)).to(dev)
-    else:
-        X = torch.empty(N, d, dtype=torch.float64, device=dev)
-    if dist is not None:
-        dist.broadcast(X, src=0)
-
-    cell = rank  # one independent cell per GPU
-    r_np, m_np = syn.cell_inputs(N, cell)
-    r, m = torch.from_numpy(r_np).to(dev), torch.from_numpy(m_np).to(dev)
-    th0, th1 = syn.theta0(cell), syn.theta_eval(cell)
-    eng = GPFitEngine(N, d, device=local_rank)
-    if rank == 0:
-        log("context ready; building V")
-    V = build_V(X, grid, th0, dev)
-    torch.cuda.synchronize(dev)
-    if rank == 0:
-        log("inputs resident; warm-up")
+    tdt = torch.float64 if dtype_name == "f64" else torch.float32
+    peak = FP64_MFMA_PEAK_TFLOPS if dtype_name == "f64" else FP32_MFMA_PEAK_TFLOPS
     logA, lam0 = syn.F_PARAMS["logA"], syn.F_PARAMS["lambda0"]
     want_grad = not args.no_grad
-    if args.dtype == "f32":
-        X, r, m, V = X.float(), r.float(), m.float(), V.float()
-    peak = FP64_MFMA_PEAK_TFLOPS if args.dtype == "f64" else FP32_MFMA_PEAK_TFLOPS
 
-    def step():
-        return eng.fit_eval(th1, lower, upper, grid, X, r, m, V, logA, lam0, want_grad=want_grad,
-                            want_vectors=False)
+    # shared stimuli: generated on rank 0, broadcast over RCCL/xGMI (16 MiB at the headline)
+    X = multi.broadcast_stimuli(torch.from_numpy(syn.stimuli(N, d)) if rank == 0 else None, (N, d), dev).to(dev)
 
+    def sync_barrier():
+        torch.cuda.synchronize(dev)
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    eng = GPFitEngine(N, d, device=local_rank)
+    extra_engines = []
+    if args.config in ("headline", "n4096"):
+        cell = rank  # one independent cell per GPU (weak scaling)
+        r_np, m_np = syn.cell_inputs(N, cell)
+        r, m = torch.from_numpy(r_np).to(dev), torch.from_numpy(m_np).to(dev)
+        th1 = syn.theta_eval(cell)
+        V = build_V(X, grid, syn.theta0(cell), dev)
+        Xd, rd, md, Vd = (t.to(tdt) for t in (X, r, m, V))
+        units_per_step, unit_name, scaling = world, "fits", "weak"
+
+        def step():
+            return eng.fit_eval(th1, lower, upper, grid, Xd, rd, md, Vd, logA, lam0, want_grad=want_grad,
+                                want_vectors=False)
+    elif args.config == "cells64":
+        cells = args.cells
+        mine = multi.partition(cells, world, rank)
+        inputs = {}
+        for c in mine:  # per-cell inputs built outside the timed region
+            rc, mc = syn.cell_inputs(N, c)
+            inputs[c] = (torch.from_numpy(rc).to(dev), torch.from_numpy(mc).to(dev), build_V(X, grid, syn.theta0(c), dev),
+                         syn.theta_eval(c))
+        engs = [eng] + [GPFitEngine(N, d, device=local_rank) for _ in range(max(1, args.depth) - 1)]
+        extra_engines = engs[1:]
+        streams = [torch.cuda.Stream(device=dev) for _ in engs]
+
+        def submit(c, slot):
+            rc, mc, Vc, thc = inputs[c]
+            with torch.cuda.stream(streams[slot]):
+                return engs[slot].fit_eval_async(thc, lower, upper, grid, X, rc, mc, Vc, logA, lam0, want_grad=want_grad,
+                                                 want_vectors=False)
+
+        def collect(ticket, slot):
+            o = engs[slot].fit_eval_finish(ticket)
+            return [o["loss"]] + [o["grad"][k] for k in syn.THETA_KEYS]
+
+        units_per_step, unit_name, scaling = cells, "cells", "strong"
+        table = [None]
+
+        def step():
+            table[0] = multi.run_sharded(cells, None, dev, submit_fn=submit, collect_fn=collect, depth=len(engs))
+            return {"loss": float(table[0][0, 0])}
+    else:  # thetagrid: one cell, 512 theta points, (r, m, V) shared -> broadcast once, V factor reused
+        npts = args.grid_points
+        points = syn.theta_grid(8)[:npts]
+        if rank == 0:
+            r_np, m_np = syn.cell_inputs(N, 0)
+            r0, m0, V0 = torch.from_numpy(r_np).to(dev), torch.from_numpy(m_np).to(dev), build_V(X, grid, syn.theta0(), dev)
+        else:
+            r0 = m0 = V0 = None
+        rd, md, Vd = multi.broadcast_state(r0, m0, V0, N, dev, dtype=tdt)
+        Vd = Vd.contiguous()
+        Xd = X.to(tdt)
+        del r0, m0, V0
+        mine = multi.partition(npts, world, rank)
+        units_per_step, unit_name, scaling = npts, "theta-points", "strong"
+        first = [True]
+
+        def eval_point(u):
+            o = eng.fit_eval(points[u], lower, upper, grid, Xd, rd, md, Vd, logA, lam0, want_grad=want_grad,
+                             want_vectors=False, reuse_V=not first[0])
+            first[0] = False
+            return [o["loss"]] + [o["grad"][k] for k in syn.THETA_KEYS]
+
+        def step():
+            t = multi.run_sharded(npts, eval_point, dev)
+            return {"loss": float(t[0, 0])}
+
+    if rank == 0:
+        log(f"config {args.config}: inputs resident; warm-up")
     for _ in range(args.warmup):
         res = step()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize(dev)
+    sync_barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         res = step()
-    torch.cuda.synchronize(dev)
-    if dist is not None:
-        dist.barrier()
+    sync_barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -209,67 +300,119 @@ def main():
     assert math.isfinite(res["loss"]), "benchmark evaluation produced a non-finite loss"
 
     if rank == 0:
-        log(f"timed region done: {elapsed / args.steps * 1e3:.2f} ms/step (host enqueue {eng.last_enqueue_ms():.2f} ms)")
-        fits_per_s = world * args.steps / elapsed
+        ms_per_step = elapsed / args.steps * 1e3
+        log(f"timed region done: {ms_per_step:.2f} ms/step (host enqueue {eng.last_enqueue_ms():.2f} ms per unit)")
+        units_per_s = units_per_step * args.steps / elapsed
         F = fits_flops(N, d)
-        # ---- roofline of the dominant kernel (fp64 MFMA GEMM family), HIP events per launch
-        eng.set_profile(True)
-        step()
+        # ---- roofline of the dominant kernel, measured live on one more unit of this rank:
+        #      HIP events around every launch of the GEMM family on the launching stream
+        if args.config == "cells64":
+            c0 = multi.partition(args.cells, world, rank)[0]
+            rc, mc, Vc, thc = inputs[c0]
+            probe = lambda: eng.fit_eval(thc, lower, upper, grid, X, rc, mc, Vc, logA, lam0, want_grad=want_grad, want_vectors=False)
+        elif args.config == "thetagrid":
+            probe = lambda: eng.fit_eval(points[0], lower, upper, grid, Xd, rd, md, Vd, logA, lam0, want_grad=want_grad, want_vectors=False)
+        else:
+            probe = step
+        eng.set_profile(1)
+        probe()
         prof = eng.get_profile()
-        eng.set_profile(False)
+        phases = None
+        if want_grad:
+            eng.set_profile(2)
+            probe()
+            phases = eng.get_phases()
+        eng.set_profile(0)
+        unit_ms = phases["end"] if phases else ms_per_step
         gemm_tflops = prof["gemm_flops"] / (prof["gemm_ms"] * 1e-3) / 1e12 if prof["gemm_ms"] > 0 else 0.0
-        # dominant kernel = the single largest launch: T = L^-1 L_V (both operands lower triangular,
-        # lower output; algorithmic flops N^3/3), the stream-K kernel
-        # gemm_streamk_kernel<R,false,true>: one call per fit, so its rocprofv3 kernel_stats row is
-        # its average (the event bracket here also covers the ~2 % fix-up kernel behind it).
+        # dominant kernel = the single largest launch: T = L^-1 L_V (both operands lower triangular, lower
+        # output; algorithmic flops N^3/3): one launch per fit of
+        # gemm_mfma_kernel<R, false, true, false, 128, 2> on the XCD-aware schedule (gemm_sched.hip), so its
+        # rocprofv3 kernel_stats row with that grid is its average.
         npad = -(-N // 128) * 128
         dom_flops = float(npad) ** 3 / 3.0
         dom_tflops = dom_flops / max(prof["largest_gemm_ms"], 1e-9) / 1e9
-        dom_name = "gemm_streamk_kernel<%s, false, true>" % ("double" if args.dtype == "f64" else "float")
+        rname = "double" if dtype_name == "f64" else "float"
+        dom_name = f"gemm_mfma_kernel<{rname}, false, true, false, 128, 2>"
+        executed = prof["gemm_flops"] + prof["small_gemm_flops"] + prof["gram_flops"]
+        nt = npad // 128
         roofline = {
             "bound": "mfma",
-            "kernel": dom_name + " (T = L^-1 L_V, N^3/3 flops, 1 launch/fit; %s)"
-                      % ("v_mfma_f64_16x16x4_f64" if args.dtype == "f64" else "v_mfma_f32_16x16x4_f32"),
+            "kernel": dom_name + " (T = L^-1 L_V, N^3/3 flops, 1 launch/fit, XCD-aware macro-tile schedule; %s)"
+                      % ("v_mfma_f64_16x16x4_f64" if dtype_name == "f64" else "v_mfma_f32_16x16x4_f32"),
             "achieved": round(dom_tflops, 2), "peak": peak, "unit": "TFLOP/s",
-            "frac": round(dom_tflops / peak, 4), "traffic": profiled_traffic(dom_name) if args.dtype == "f64" else None,
+            "frac": round(dom_tflops / peak, 4),
+            "traffic": profiled_traffic(dom_name, blocks=None) if dtype_name == "f64" else None,
+            "mfma_util": profiled_mfma_util(dom_name) if dtype_name == "f64" else None,
             "launches_per_fit": 1, "avg_launch_ms": round(prof["largest_gemm_ms"], 4),
             "algorithmic_flops_per_launch": dom_flops,
             "gemm_family": {"what": "all 128-tile GEMM/SYRK/TRSM/TRTRI launches (gemm_mfma_kernel<..,128> + gemm_streamk_kernel), executed flops",
                             "launches_per_fit": prof["gemm_launches"], "tflops": round(gemm_tflops, 2),
                             "frac": round(gemm_tflops / peak, 4),
                             "avg_launch_ms": round(prof["gemm_ms"] / max(1, prof["gemm_launches"]), 4)},
-            "flops_executed_per_fit": prof["gemm_flops"] + prof["small_gemm_flops"] + prof["gram_flops"],
+            # whole unit: flops the implementation EXECUTES (2.77 N^3 formulation, tile granularity) over the
+            # unit's wall time -- the honest utilisation of the matrix peak by the unit of work
+            "flops_executed_per_fit": executed,
+            "unit_ms": round(unit_ms, 3),
+            "unit_executed_tflops": round(executed / (unit_ms * 1e-3) / 1e12, 2),
+            "unit_executed_frac": round(executed / (unit_ms * 1e-3) / 1e12 / peak, 4),
+            "phases_ms": phases,
             "gemm_ms_per_fit": round(prof["gemm_ms"], 3), "leaf_ms_per_fit": round(prof["leaf_ms"], 3),
+            "leaf_launches_per_fit": prof["leaf_launches"],
             "small_tile_gemm": {"launches_per_fit": prof["small_gemm_launches"], "ms_per_fit": round(prof["small_gemm_ms"], 3),
                                 "tflops": round(prof["small_gemm_flops"] / max(prof["small_gemm_ms"], 1e-9) / 1e9, 2)},
             "gram_ms_per_fit": round(prof["gram_ms"], 3),
+            # SURVEY 8(d)'s algorithmic flop count F_fit = (14/3)N^3 + ... over the unit's time: a speed-up
+            # figure against the textbook formulation (the implementation executes 0.61 of it), NOT a
+            # fraction of peak
             "unit_algorithmic_flops": F,
-            "unit_achieved_tflops": round(F * fits_per_s / world / 1e12, 2),
-            "unit_frac_of_peak": round(F * fits_per_s / world / 1e12 / peak, 4),
+            "unit_algorithmic_tflops_equivalent": round(F / (unit_ms * 1e-3) / 1e12, 2),
         }
+        metric = {"headline": "GP fits/sec (kernel+chol+solve+grad loglik) at N=8192 d=256",
+                  "n4096": "GP fits/sec (kernel+chol+solve+grad loglik) at N=4096 d=128",
+                  "cells64": "cells/sec, 64 independent cells x N=4096 d=128 sharded over the GPUs",
+                  "thetagrid": "theta-points/sec, 512-point hyperparameter grid x N=8192 d=256 with gradients"}[args.config]
+        workload = {"headline": f"N={N} d={d} single cell {dtype_name}, one M-step closure evaluation with 6 gradients (BASELINE configs[2], headline)",
+                    "n4096": f"N={N} d={d} single cell {dtype_name}, one M-step closure evaluation with 6 gradients (BASELINE configs[1])",
+                    "cells64": f"{args.cells} independent cells x N={N} d={d} {dtype_name}, cyclic shard over the ranks, X broadcast once, "
+                               f"{max(1, args.depth)} cells in flight per GPU (BASELINE configs[3])",
+                    "thetagrid": f"{args.grid_points} theta points x N={N} d={d} {dtype_name} with gradients, cyclic shard over the ranks, "
+                                 f"X, r, m, V broadcast once, V factor reused across points (BASELINE configs[4])"}[args.config]
+        if not want_grad:
+            workload += " [forward only]"
         out = {
-            "metric": "GP fits/sec (kernel+chol+solve+grad loglik) at N=8192 d=256" + ("" if args.dtype == "f64" else " [fp32 instance]"),
-            "value": round(fits_per_s, 4), "unit": "fits/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": f"N={N} d={d} single cell {'fp64' if args.dtype == 'f64' else 'fp32'}, one M-step closure evaluation with 6 gradients "
-                                   "(BASELINE configs[2], headline)" if want_grad else f"N={N} d={d} forward only",
-                       "N": N, "d": d, "cells_per_gpu": 1, "parallelism": f"independent cells x{world}, X broadcast once over RCCL"},
+            "metric": metric + ("" if (dtype_name == "f64") == (args.config != "thetagrid") else f" [{dtype_name} instance]"),
+            "value": round(units_per_s, 4), "unit": f"{unit_name}/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
+            "scaling": scaling, "vs_baseline": None, "dtype": dtype_name, "data": "synthetic",
+            "config": {"workload": workload, "N": N, "d": d, "units_per_step": units_per_step,
+                       "parallelism": f"independent units over {world} GPU(s), one process per GPU, no data-path collective"},
             "loss": res["loss"],
             "roofline": roofline,
         }
-        if world == 1 and not args.no_cpu_baseline and args.dtype == "f64":
-            cb = cpu_baseline(args.cpu_sample_n, d)
-            scale = (N / cb["n"]) ** 3
+        if world == 1 and not args.no_cpu_baseline and dtype_name == "f64" and args.config == "headline":
+            cores, small, full = cpu_baseline(N, d, min(args.cpu_sample_n, N), args.cpu_quick)
+            scale = (N / small["n"]) ** 3
+            if full is not None:
+                t_unit, how = full["t_ref"], (f"ONE real evaluation at N={N} d={d}: {full['t_ref']:.1f} s; plus 3 timed repeats (after a warm-up) at "
+                                              f"N={small['n']}: {small['t_ref_all']} s (median {small['t_ref']:.2f} s, x{scale:.0f} by N^3 = {small['t_ref'] * scale:.1f} s)")
+            else:
+                t_unit, how = small["t_ref"] * scale, (f"3 timed repeats (after a warm-up) at N={small['n']} d={d}: {small['t_ref_all']} s, "
+                                                      f"median {small['t_ref']:.2f} s scaled x{scale:.0f} (N^3) to N={N}")
+            gpu_fits = units_per_s / world
             out["cpu_baseline"] = {
-                "value": round(1.0 / (cb["t_ref"] * scale), 6), "unit": "fits/s", "cores": cb["cores"], "kind": "port",
-                "sample": f"reference-formulation closure (oracle.mstep_closure_reference, torch CPU fp64) at N={cb['n']} "
-                          f"d={d}: {cb['t_ref']:.2f} s/eval (best of {cb['repeats']}), scaled x{scale:.0f} (N^3) to N={N}",
-                "sample_seconds_per_eval": round(cb["t_ref"], 3),
-                "cholesky_port_seconds_per_eval": round(cb["t_chol"], 3),
-                "gpu_vs_cpu": round(fits_per_s * cb["t_ref"] * scale, 1),
+                "value": round(1.0 / t_unit, 6), "unit": "fits/s", "cores": cores, "kind": "port",
+                "sample": "reference-formulation closure (oracle.mstep_closure_reference: materialised dK{6}, eigen-projection, "
+                          "LU inverse, 13+13 gradient GEMMs; torch CPU fp64): " + how,
+                "seconds_per_eval_at_sample_n": small["t_ref_all"],
+                "seconds_per_eval_full_n": round(full["t_ref"], 2) if full else None,
+                "cholesky_port_seconds_per_eval": {"n": (full or small)["n"], "s": round((full or small)["t_chol"], 3)},
+                "gpu_vs_cpu": round(gpu_fits * t_unit, 1),
+                "gpu_vs_cpu_cholesky_port": round(gpu_fits * (full or small)["t_chol"] * (1.0 if full else scale), 1),
             }
         print(json.dumps(out), flush=True)
+    for e in extra_engines:
+        e.close()
     eng.close()
     if dist is not None:
         dist.destroy_process_group()

@@ -20,7 +20,8 @@ static thread_local void* g_main_sk_ws = nullptr;  // stream-K workspace of the 
 
 // tile-walk choices of the large launches (tuning knob GPFIT_WALKS = trsm,tmp,merge,T,Q,Rbase,H)
 static const int* walks() {
-  static int w[7] = {3, 2, 1, 1, 1, 2, 2};
+  static int w[7] = {3, 2, 1, 9, 9, 2, 2};  // bit 3 = XCD-aware macro-tile schedule where the launch is large enough
+                                          // (gemm_sched.hip), else the walk in the low bits
   static bool init = false;
   if (!init) {
     init = true;
@@ -366,7 +367,11 @@ static int fit_eval_impl(gpfit_ctx* c, void* stream, const double* theta, const 
     GP_HIP(hipStreamWaitEvent(sa, c->ev_fork, 0));
   }
   // tuning knob: smallest block whose inverse-merge product goes to the side stream (0 = never)
-  static const int side_min = getenv("GPFIT_SIDE_MIN") ? atoi(getenv("GPFIT_SIDE_MIN")) : 1024;
+  // (only for synchronous calls: with several units in flight on several contexts the chip is busy
+  // anyway and four more streams per context oversubscribe the hardware queues -- 64 cells x N = 4096,
+  // four in flight: 161 -> 118 cells/s with side streams)
+  static const int side_min_env = getenv("GPFIT_SIDE_MIN") ? atoi(getenv("GPFIT_SIDE_MIN")) : 1024;
+  const int side_min = async_call ? 0 : side_min_env;
   // tuning knob (bit mask): 1 = the V chain's own 128-tile launches at one workgroup per CU, 2 = the
   // side-stream products of both chains
   static const int half_occ = getenv("GPFIT_HALF_OCC") ? atoi(getenv("GPFIT_HALF_OCC")) : 0;
@@ -435,10 +440,10 @@ static int fit_eval_impl(gpfit_ctx* c, void* stream, const double* theta, const 
     //   W = 1/2 Li^T Q Li  two-sided product (two_sided above)   13/12 N^3 with one split
     //                      (direct: R = Q Li, W = 1/2 Li^T R     4/3 N^3)
     {
-      // T T^T: every tile of a tile column has the same k range [0, col + 128), so the column-major
-      // heavy-first data-parallel launch keeps a column's workgroups in lock step on its B panel
-      // (2.81 vs 2.98 ms at N = 8192); below ~6000 the launch is too small to balance without stream-K
-      static const int q_plain_min = getenv("GPFIT_Q_PLAIN_MIN") ? atoi(getenv("GPFIT_Q_PLAIN_MIN")) : 6144;
+      // T T^T: every tile of a tile column has the same k range [0, col + 128).  XCD-aware macro-tile
+      // schedule (2.97 ms at N = 8192 in the fit; the column-major heavy-first data-parallel walk 3.02,
+      // stream-K 3.2); GPFIT_Q_PLAIN_MIN restores the column-major walk above that size
+      static const int q_plain_min = getenv("GPFIT_Q_PLAIN_MIN") ? atoi(getenv("GPFIT_Q_PLAIN_MIN")) : (1 << 30);
       const bool dp = np >= q_plain_min;
       GP_TRY(gemm<R>(s, 0, 0, np, np, np, -1.0, RP(c->Tbuf), ld, RP(c->Tbuf), ld, 0.0, RP(c->Wbuf), ld, 1, 1, 2,
                      dp ? 3 : walks()[4], 0, nullptr, dp));

@@ -52,8 +52,8 @@ static int build(const GemmArgsT<R>& a, Plan& plan) {
   };
   // tuning knobs: macro-tile rows x columns, and the weight (as a fraction 1/cutdiv of a queue's
   // average load) below which a macro-tile is split into quarters
-  static const int gr_env = getenv("GPFIT_XCD_GR") ? atoi(getenv("GPFIT_XCD_GR")) : 4;
-  static const int gc_env = getenv("GPFIT_XCD_GC") ? atoi(getenv("GPFIT_XCD_GC")) : 4;
+  static const int gr_env = getenv("GPFIT_XCD_GR") ? atoi(getenv("GPFIT_XCD_GR")) : 2;
+  static const int gc_env = getenv("GPFIT_XCD_GC") ? atoi(getenv("GPFIT_XCD_GC")) : 2;
   static const int cutdiv = getenv("GPFIT_XCD_CUT") ? atoi(getenv("GPFIT_XCD_CUT")) : 8;
   const int GR = std::max(1, std::min(gr_env, 32)), GC = std::max(1, std::min(gc_env, 32));
   // macro-tiles; every tile carries one k step of fixed cost (prologue / epilogue) in its weight
@@ -115,6 +115,10 @@ int launch_gemm_xcd(const GemmArgsT<R>& a, hipStream_t s) {
   if (a.out_lower && a.M != a.N) return 1;
   const long tm = a.M / TILE, tn = a.N / TILE;
   if (tm >= 32768 || tn >= 32768) return 1;
+  // A data-parallel schedule needs several rounds of the 512 resident workgroups to balance; below
+  // that the stream-K / heavy-first walks win (N = 4096: 528 tiles, 7.27 vs 7.5 ms per fit).
+  static const long min_tiles = getenv("GPFIT_XCD_MIN_TILES") ? atol(getenv("GPFIT_XCD_MIN_TILES")) : 1536;
+  if ((a.out_lower ? tm * (tm + 1) / 2 : tm * tn) < min_tiles) return 1;
   int device = 0;
   GP_HIP(hipGetDevice(&device));
   Plan plan;
