@@ -140,7 +140,7 @@ int gpfit_acosker_pullback(gpfit_ctx* c, void* stream, double sigma0, const doub
   double* X1m = c->Xm;     // [np1][dp] row-major copies of the operands
   double* X2m = c->XDt;    // the [dp][np] scratch matrices have the same element count
   double* Zm = c->XDt2;
-  c->lv_valid = false;
+  c->lv_valid = false; c->lv32_valid = false;
   // forward pieces: q1, q2, the cosine matrix
   GP_TRY(launch_pad_copy(C, ldC, (int)d, (int)d, c->Cmat, dp, dp, dp, s));
   GP_TRY(launch_gather<double>(x1, ld1, (int)n1, nullptr, (int)d, dp, np1, c->Xt, np1, X1m, dp, s));

@@ -56,6 +56,7 @@ struct gpfit_ctx {
   // cached state of the last upload / evaluation (used by estep / predict entry points)
   int cur_n = 0, cur_np = 0, cur_d = 0, cur_dp = 0;
   bool lv_valid = false;  // LVbuf / scal[40] hold the factor and log-det of the last V
+  bool lv32_valid = false;  // Vbuf holds the single-precision copy of that factor (mixed-precision mode)
   int lv_n = 0;
   int lv_bytes = 0;       // element size the cached factor was computed in
 };

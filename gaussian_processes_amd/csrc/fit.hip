@@ -289,6 +289,79 @@ static int dev_alloc(gpfit_ctx* c, T** p, size_t count) {
   return 0;
 }
 
+// Everything after the join of the two factorisation chains: T = L^-1 L_V and its norm, and (with
+// gradients) Q = I - T T^T, the two-sided product W, the adjoint pass and the pull-back to the metric.
+// Templated separately from the first half of the unit so that the mixed-precision mode (fp64
+// factorisations, fp32 gradient products) can run it on single-precision copies.
+template <typename R>
+struct PostJoin {
+  const R *Li, *LV, *Cos, *bv, *q, *wl, *Xm, *Cmat;           // inputs
+  R *T, *W, *Z, *H, *A, *Y, *tvec, *Mpart, *Mmat;             // work matrices (np^2), Y [np][dp], Mpart / Mmat
+};
+template <typename R, typename PhaseFn>
+static int post_join(gpfit_ctx* c, const PostJoin<R>& a, const Theta& th, int n, int np, int d, int dp, int n_rows,
+                     int n_cols, int want_grad, hipStream_t s, PhaseFn&& phase) {
+  const int64_t ld = np;
+  // T = L^-1 L_V (lower x lower -> lower);  tr(K~^-1 V) = ||T||_F^2
+  {
+    static const int t_plain_min = getenv("GPFIT_T_PLAIN_MIN") ? atoi(getenv("GPFIT_T_PLAIN_MIN")) : (1 << 30);
+    static const int t_plain_walk = getenv("GPFIT_T_PLAIN_WALK") ? atoi(getenv("GPFIT_T_PLAIN_WALK")) : 6;
+    const bool dp = np >= t_plain_min;
+    GP_TRY(gemm<R>(s, 0, 1, np, np, np, 1.0, a.Li, ld, a.LV, ld, 0.0, a.T, ld, 1, 1, 1,
+                   dp ? t_plain_walk : walks()[3], 0, nullptr, dp));
+  }
+  GP_TRY(launch_frob_lower(a.T, ld, np, c->scal + 5, c->frob_part, s));
+  phase(4, s);
+
+  if (want_grad) {
+    // W = 1/2 (K~^-1 - K~^-1 V K~^-1) = 1/2 Li^T (I - T T^T) Li        (T = L^-1 L_V)
+    //   Q = I - T T^T   lower x upper, lower tiles only          N^3/3
+    //   W = 1/2 Li^T Q Li  two-sided product (two_sided above)   13/12 N^3 with one split
+    //                      (direct: R = Q Li, W = 1/2 Li^T R     4/3 N^3)
+    {
+      // T T^T: every tile of a tile column has the same k range [0, col + 128).  XCD-aware macro-tile
+      // schedule (2.97 ms at N = 8192 in the fit; the column-major heavy-first data-parallel walk 3.02,
+      // stream-K 3.2); GPFIT_Q_PLAIN_MIN restores the column-major walk above that size
+      static const int q_plain_min = getenv("GPFIT_Q_PLAIN_MIN") ? atoi(getenv("GPFIT_Q_PLAIN_MIN")) : (1 << 30);
+      const bool dp = np >= q_plain_min;
+      GP_TRY(gemm<R>(s, 0, 0, np, np, np, -1.0, a.T, ld, a.T, ld, 0.0, a.W, ld, 1, 1, 2,
+                     dp ? 3 : walks()[4], 0, nullptr, dp));
+    }
+    GP_TRY(launch_add_diag(a.W, ld, np, 1.0, s));
+    GP_TRY(launch_symmetrize(a.W, ld, np, s));
+    phase(5, s);
+    {
+      static const int ts_min = getenv("GPFIT_TS_MIN") ? atoi(getenv("GPFIT_TS_MIN")) : 4096;
+      TwoSidedBufs<R> tb{a.W, a.Li, a.T, a.Z, a.H, ld, ts_min > 0 ? ts_min : (1 << 30)};
+      GP_TRY(two_sided<R>(tb, 0, np, s));
+    }
+    phase(6, s);
+    GP_TRY(launch_adjoint(a.T, a.Cos, ld, a.bv, a.q, n, np, a.A, c->upart, c->vpart, c->sumA_part, s));
+    const int t64 = np / 64;
+    GP_TRY(launch_adjoint_reduce(c->upart, c->vpart, c->sumA_part, t64, t64 * (t64 + 1) / 2, a.q, a.wl, n, np,
+                                 a.tvec, c->rpad, c->scal + 7, s));
+    // pull the contraction with dK~ back to the d x d metric: M = X^T (Aw + diag t) X
+    GP_TRY(gemm<R>(s, 1, 1, np, dp, np, 1.0, a.A, ld, a.Xm, dp, 0.0, a.Y, dp, 0, 0, 0));
+    GP_TRY(launch_rowscale_add(a.Y, dp, a.Xm, dp, a.tvec, np, dp, s));
+    {
+      GemmArgsT<R> g{};
+      g.A = a.Xm; g.B = a.Y; g.C = a.Mpart;
+      g.lda = dp; g.ldb = dp; g.ldc = dp;
+      g.M = dp; g.N = dp; g.K = np;
+      g.alpha = 1.0; g.beta = 0.0; g.a_kmajor = 1; g.b_kmajor = 1;
+      g.batch = 1; g.split_k = c->split_k_M; g.sC = (int64_t)dp * dp;
+      {
+        ProfScope ps(s, g_prof ? gemm_flops(g) : 0.0, (g_prof && gemm_pick_tile(g) != TILE) ? 3 : 0);
+        GP_TRY(launch_gemm(g, s));
+      }
+      GP_TRY(launch_reduce_slices(a.Mpart, (int64_t)dp * dp, c->split_k_M, a.Mmat, (int64_t)dp * dp, s));
+    }
+    GP_TRY(launch_metric_contract(th, c->pix, d, n_rows, n_cols, a.Cmat, dp, a.Mmat, dp, c->scal + 10, s));
+  }
+
+  return 0;
+}
+
 // The fused unit of work, templated on the scalar type of the device data: fp64 is the
 // reference's precision (headline); fp32 serves the hyperparameter-grid configuration
 // (BASELINE configs[4]) -- every matrix, factorisation and GEMM in fp32 on v_mfma_f32_16x16x4_f32,
@@ -356,6 +429,7 @@ static int fit_eval_impl(gpfit_ctx* c, void* stream, const double* theta, const 
   // log|V| are kept.  bench.py never sets it: the unit of work includes this factorisation.
   const bool reuse_V = (want_grad & 2) && c->lv_valid && c->lv_n == n && c->lv_bytes == (int)sizeof(R);
   const bool async_call = (want_grad & 4) != 0;
+  const bool mixed_grad = (want_grad & 8) != 0 && sizeof(R) == 8 && (want_grad & 1);
   want_grad &= 1;
   // The V chain starts together with potrf(K~), not at the top of the call: the two recursions have
   // the same shape, so started together their leaf phases and their large GEMMs coincide -- a large
@@ -378,7 +452,7 @@ static int fit_eval_impl(gpfit_ctx* c, void* stream, const double* theta, const 
   c->side_ev_next[0] = c->side_ev_next[1] = 0;
   auto enqueue_v_chain = [&]() -> int {
   if (!reuse_V) {
-      c->lv_valid = false;
+      c->lv_valid = false; c->lv32_valid = false;
       GP_TRY(launch_pack_lower(V, ldv, n, RP(c->Vbuf), ld, np, sa));
       CholBufsT<R> bv{RP(c->Vbuf), RP(c->LVbuf), RP(c->LiVbuf), RP(c->TmpV), ld, c->info + 1, 1, c->sk_ws[1], c, 1, side_min, half_occ & 3};
       GP_TRY(potrf_rec<R>(bv, 0, np, false, sa));
@@ -423,61 +497,33 @@ static int fit_eval_impl(gpfit_ctx* c, void* stream, const double* theta, const 
   phase(2, s);
   // ---- join: everything that needs both factors
   GP_HIP(hipStreamWaitEvent(s, c->ev_join, 0));
-  // T = L^-1 L_V (lower x lower -> lower);  tr(K~^-1 V) = ||T||_F^2
   {
-    static const int t_plain_min = getenv("GPFIT_T_PLAIN_MIN") ? atoi(getenv("GPFIT_T_PLAIN_MIN")) : (1 << 30);
-    static const int t_plain_walk = getenv("GPFIT_T_PLAIN_WALK") ? atoi(getenv("GPFIT_T_PLAIN_WALK")) : 6;
-    const bool dp = np >= t_plain_min;
-    GP_TRY(gemm<R>(s, 0, 1, np, np, np, 1.0, RP(c->Libuf), ld, RP(c->LVbuf), ld, 0.0, RP(c->Tbuf), ld, 1, 1, 1,
-                   dp ? t_plain_walk : walks()[3], 0, nullptr, dp));
-  }
-  GP_TRY(launch_frob_lower(RP(c->Tbuf), ld, np, c->scal + 5, c->frob_part, s));
-  phase(4, s);
-
-  if (want_grad) {
-    // W = 1/2 (K~^-1 - K~^-1 V K~^-1) = 1/2 Li^T (I - T T^T) Li        (T = L^-1 L_V)
-    //   Q = I - T T^T   lower x upper, lower tiles only          N^3/3
-    //   W = 1/2 Li^T Q Li  two-sided product (two_sided above)   13/12 N^3 with one split
-    //                      (direct: R = Q Li, W = 1/2 Li^T R     4/3 N^3)
-    {
-      // T T^T: every tile of a tile column has the same k range [0, col + 128).  XCD-aware macro-tile
-      // schedule (2.97 ms at N = 8192 in the fit; the column-major heavy-first data-parallel walk 3.02,
-      // stream-K 3.2); GPFIT_Q_PLAIN_MIN restores the column-major walk above that size
-      static const int q_plain_min = getenv("GPFIT_Q_PLAIN_MIN") ? atoi(getenv("GPFIT_Q_PLAIN_MIN")) : (1 << 30);
-      const bool dp = np >= q_plain_min;
-      GP_TRY(gemm<R>(s, 0, 0, np, np, np, -1.0, RP(c->Tbuf), ld, RP(c->Tbuf), ld, 0.0, RP(c->Wbuf), ld, 1, 1, 2,
-                     dp ? 3 : walks()[4], 0, nullptr, dp));
+    PostJoin<R> pj{RP(c->Libuf), RP(c->LVbuf), RP(c->Cos), RP(c->bv), RP(c->q), RP(c->wl), RP(c->Xm), RP(c->Cmat),
+                   RP(c->Tbuf), RP(c->Wbuf), RP(c->Zbuf), RP(c->Tmp), RP(c->Abuf), RP(c->Ybuf), RP(c->tvec),
+                   RP(c->Mpart), RP(c->Mmat)};
+    if (mixed_grad) {
+      // fp64 factorisations (everything the loss depends on), fp32 for the N^3-heavy gradient products:
+      // single-precision copies of the factors and of the O(N^2) / O(N) operands of the adjoint pass.
+      // Li -> Kbuf (its input was destroyed by the factorisation), L_V -> Vbuf (likewise; kept while the
+      // V factor is reused), cos(delta) -> TmpV, vectors and the d x d metric into spare buffers.
+      auto F = [](double* b) { return reinterpret_cast<float*>(b); };
+      const int64_t nn = (int64_t)np * np;
+      GP_TRY((launch_reduce_slices<double, float>(c->Libuf, nn, 1, F(c->Kbuf), nn, s)));
+      if (!(reuse_V && c->lv32_valid)) GP_TRY((launch_reduce_slices<double, float>(c->LVbuf, nn, 1, F(c->Vbuf), nn, s)));
+      c->lv32_valid = true;
+      GP_TRY((launch_reduce_slices<double, float>(c->Cos, nn, 1, F(c->TmpV), nn, s)));
+      GP_TRY((launch_reduce_slices<double, float>(c->bv, np, 1, F(c->q2), np, s)));
+      GP_TRY((launch_reduce_slices<double, float>(c->q, np, 1, F(c->dq1), np, s)));
+      GP_TRY((launch_reduce_slices<double, float>(c->wl, np, 1, F(c->dq2), np, s)));
+      GP_TRY((launch_reduce_slices<double, float>(c->Xm, (int64_t)np * dp, 1, F(c->Xt2), (int64_t)np * dp, s)));
+      GP_TRY((launch_reduce_slices<double, float>(c->Cmat, (int64_t)dp * dp, 1, F(c->dCpad), (int64_t)dp * dp, s)));
+      PostJoin<float> pf{F(c->Kbuf), F(c->Vbuf), F(c->TmpV), F(c->q2), F(c->dq1), F(c->dq2), F(c->Xt2), F(c->dCpad),
+                         F(c->Tbuf), F(c->Wbuf), F(c->Zbuf), F(c->Tmp), F(c->Abuf), F(c->Ybuf), F(c->tvec),
+                         F(c->Mpart), F(c->Mmat)};
+      GP_TRY(post_join<float>(c, pf, th, n, np, d, dp, n_rows, n_cols, want_grad, s, phase));
+    } else {
+      GP_TRY(post_join<R>(c, pj, th, n, np, d, dp, n_rows, n_cols, want_grad, s, phase));
     }
-    GP_TRY(launch_add_diag(RP(c->Wbuf), ld, np, 1.0, s));
-    GP_TRY(launch_symmetrize(RP(c->Wbuf), ld, np, s));
-    phase(5, s);
-    {
-      static const int ts_min = getenv("GPFIT_TS_MIN") ? atoi(getenv("GPFIT_TS_MIN")) : 4096;
-      TwoSidedBufs<R> tb{RP(c->Wbuf), RP(c->Libuf), RP(c->Tbuf), RP(c->Zbuf), RP(c->Tmp), ld, ts_min > 0 ? ts_min : (1 << 30)};
-      GP_TRY(two_sided<R>(tb, 0, np, s));
-    }
-    phase(6, s);
-    GP_TRY(launch_adjoint(RP(c->Tbuf), RP(c->Cos), ld, RP(c->bv), RP(c->q), n, np, RP(c->Abuf), c->upart, c->vpart, c->sumA_part, s));
-    const int t64 = np / 64;
-    GP_TRY(launch_adjoint_reduce(c->upart, c->vpart, c->sumA_part, t64, t64 * (t64 + 1) / 2, RP(c->q), RP(c->wl), n, np,
-                                 RP(c->tvec), c->rpad, c->scal + 7, s));
-    // pull the contraction with dK~ back to the d x d metric: M = X^T (Aw + diag t) X
-    GP_TRY(gemm<R>(s, 1, 1, np, dp, np, 1.0, RP(c->Abuf), ld, RP(c->Xm), dp, 0.0, RP(c->Ybuf), dp, 0, 0, 0));
-    GP_TRY(launch_rowscale_add(RP(c->Ybuf), dp, RP(c->Xm), dp, RP(c->tvec), np, dp, s));
-    {
-      GemmArgsT<R> g{};
-      g.A = RP(c->Xm); g.B = RP(c->Ybuf); g.C = RP(c->Mpart);
-      g.lda = dp; g.ldb = dp; g.ldc = dp;
-      g.M = dp; g.N = dp; g.K = np;
-      g.alpha = 1.0; g.beta = 0.0; g.a_kmajor = 1; g.b_kmajor = 1;
-      g.batch = 1; g.split_k = c->split_k_M; g.sC = (int64_t)dp * dp;
-      {
-        ProfScope ps(s, g_prof ? gemm_flops(g) : 0.0, (g_prof && gemm_pick_tile(g) != TILE) ? 3 : 0);
-        GP_TRY(launch_gemm(g, s));
-      }
-      GP_TRY(launch_reduce_slices(RP(c->Mpart), (int64_t)dp * dp, c->split_k_M, RP(c->Mmat), (int64_t)dp * dp, s));
-    }
-    GP_TRY(launch_metric_contract(th, c->pix, d, n_rows, n_cols, RP(c->Cmat), dp, RP(c->Mmat), dp, c->scal + 10, s));
   }
 
   if (lam_m_out) GP_HIP(hipMemcpyAsync(lam_m_out, RP(c->lam_m), (size_t)n * sizeof(R), hipMemcpyDeviceToDevice, s));
@@ -525,7 +571,7 @@ static int grad_pullback_impl(gpfit_ctx* c, void* stream, const double* theta, i
   const Theta th = make_theta(theta);
   const double s0sq = th.sigma0 * th.sigma0;
   const int64_t ld = np;
-  c->lv_valid = false;  // the workspace matrices are reused
+  c->lv_valid = false; c->lv32_valid = false;  // the workspace matrices are reused
   g_main_sk_ws = c->sk_ws[0];
   GP_HIP(hipMemcpyAsync(c->pix, c->pix_host, (size_t)d * sizeof(int), hipMemcpyHostToDevice, s));
   GP_TRY(launch_localker<R>(th, c->pix, d, dp, n_rows, n_cols, RP(c->Cmat), dp, nullptr, s));

@@ -101,7 +101,7 @@ class GPFitEngine:
         return torch.tensor(list(buf), dtype=torch.bool), int(d.value)
 
     def fit_eval(self, theta, lower, upper, n_px_side, X, r, m, V, logA, lambda0, want_grad=True,
-                 want_vectors=True, reuse_V=False):
+                 want_vectors=True, reuse_V=False, grad_precision="native"):
         """One evaluation of the M-step closure (utils.py:2017-2112), full-rank regime.
 
         Returns a dict with ``loss`` (= -logmarginal), ``loglik``, ``KL``, ``grad`` (dict in the
@@ -110,12 +110,14 @@ class GPFitEngine:
         (hyperparameter-grid configuration); float64 is the reference's precision.  Out-of-box theta returns loss = inf and grad = inf (reference
         behaviour); a failed Cholesky raises ``GpfitError``.  ``reuse_V=True`` promises that V is
         the matrix of the previous call on this engine (constant during an M-step) so that its
-        factorisation is not repeated."""
+        factorisation is not repeated.  ``grad_precision="f32"`` (float64 inputs) keeps the kernel build, both
+        factorisations and the loss in fp64 and runs the gradient's N^3 products in fp32."""
         return self.fit_eval_finish(self.fit_eval_async(theta, lower, upper, n_px_side, X, r, m, V, logA, lambda0,
-                                                        want_grad, want_vectors, reuse_V, _sync=True))
+                                                        want_grad, want_vectors, reuse_V, _sync=True,
+                                                        grad_precision=grad_precision))
 
     def fit_eval_async(self, theta, lower, upper, n_px_side, X, r, m, V, logA, lambda0, want_grad=True,
-                       want_vectors=True, reuse_V=False, _sync=False):
+                       want_vectors=True, reuse_V=False, _sync=False, grad_precision="native"):
         """Enqueue one evaluation on the current stream without waiting for it; returns a ticket
         for :meth:`fit_eval_finish`.  One evaluation may be pending per engine: independent units
         (cells, theta points) are overlapped by alternating between engines on different streams
@@ -138,7 +140,11 @@ class GPFitEngine:
         lo = _lib.darr(theta_vec(lower)) if lower is not None else None
         up = _lib.darr(theta_vec(upper)) if upper is not None else None
         entry = self.lib.gpfit_fit_eval_f32 if dtype == torch.float32 else self.lib.gpfit_fit_eval
-        flags = (1 if want_grad else 0) | (2 if reuse_V else 0) | (0 if _sync else 4)
+        if grad_precision not in ("native", "f32"):
+            raise ValueError("grad_precision must be 'native' or 'f32'")
+        if grad_precision == "f32" and dtype != torch.float64:
+            raise ValueError("grad_precision='f32' is the mixed mode of the fp64 entry point: pass float64 inputs")
+        flags = (1 if want_grad else 0) | (2 if reuse_V else 0) | (0 if _sync else 4) | (8 if grad_precision == "f32" else 0)
         rc = entry(self._ctx, self._stream(), _lib.darr(theta_vec(theta)), lo, up, rows, cols,
                    X.data_ptr(), X.stride(0), N, r.data_ptr(), m.data_ptr(), V.data_ptr(),
                    V.stride(0), float(logA), float(lambda0), flags, out, ptrs[0], ptrs[1], ptrs[2])

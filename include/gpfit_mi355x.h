@@ -122,7 +122,11 @@ int gpfit_acosker_diag(gpfit_ctx* ctx, void* stream, double sigma0, const double
  * asynchronous: only enqueue on `stream` and return (out_host is not written); the caller collects
  * the result with gpfit_fit_eval_finish.  Independent units (other cells, other theta points) can
  * then be kept in flight on several contexts / streams, so that one unit's latency-bound
- * factorisation overlaps another's GEMMs (multi.py).
+ * factorisation overlaps another's GEMMs (multi.py); bit 3 = mixed precision (fp64 entry point only):
+ * kernel build, both Cholesky factorisations and every scalar of the loss in fp64, the N^3-heavy
+ * products of the gradient (T, Q, W and the pull-back) in fp32 on single-precision copies of the
+ * factors -- the hyperparameter-grid configuration (BASELINE configs[4]) at the north star's 1e-5
+ * bar on the log marginal likelihood, which the all-fp32 instance misses on some grid points.
  * lam_m/lam_var/f (device, [N]) may be NULL.  Synchronises `stream` before returning unless bit 2.
  * Returns 0; -2 when theta is outside [lower, upper] (out_host[0] = +inf and gradients
  * +inf, exactly what the reference closure hands to L-BFGS); > 0 LAPACK info. */

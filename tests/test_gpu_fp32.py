@@ -2,7 +2,7 @@
 configs[4]) against the fp64 path on the same inputs.  The reference has no fp32 mode
 (utils.py:31-33), so the fp64 result -- itself pinned to the reference -- is the yardstick.
 
-Stated tolerances (measured agreement is ~10x tighter): loss / loglik / KL 2e-5 relative,
+Stated tolerances: loss 1e-5 relative (the north star's bar), its parts loglik / KL 2e-5 relative,
 gradients 2e-3 of the largest component, posterior vectors 1e-4 relative.  cond(K~) ~ 5e5 at
 N=8192, i.e. fp32 loses ~1e-2 in the weakest eigen-directions but the log-determinant, traces
 and quadratic forms are dominated by the well-conditioned ones."""
@@ -44,13 +44,91 @@ def test_fp32_unit_of_work_tracks_fp64(N, d):
     b = eng.fit_eval(th1, LOWER, UPPER, grid, f32(X), f32(r), f32(m), f32(V), LOGA, LAM0)
     eng.close()
     assert b["lam_m"].dtype == torch.float32
-    for key in ("loss", "loglik", "KL"):
+    assert abs(b["loss"] - a["loss"]) <= 1e-5 * abs(a["loss"]), (a["loss"], b["loss"])   # the north star's bar
+    for key in ("loglik", "KL"):
         assert abs(b[key] - a[key]) <= 2e-5 * abs(a[key]), (key, a[key], b[key])
     ga = np.array([a["grad"][k] for k in KEYS]); gb = np.array([b["grad"][k] for k in KEYS])
     assert np.abs(ga - gb).max() <= 2e-3 * np.abs(ga).max(), (ga, gb)
     assert relerr(b["lam_var"].double().cpu().numpy(), a["lam_var"].cpu().numpy()) < 1e-4
     assert relerr(b["f"].double().cpu().numpy(), a["f"].cpu().numpy()) < 1e-4
     print(f"N={N} d={d}: loss rel {abs(b['loss']-a['loss'])/abs(a['loss']):.2e} grad rel {np.abs(ga-gb).max()/np.abs(ga).max():.2e}")
+
+
+def stratified_lattice_points():
+    """64 of the 512 lattice points of BASELINE configs[4] (8 x 8 x 8 over -2log2beta, -log2rho2, Amp,
+    +-0.35 around theta0): the 8 corners plus 56 points that cover every level of every axis
+    (a 4 x 4 x 4 sub-lattice on the even levels shifted cyclically, minus duplicates of corners)."""
+    pts = syn.theta_grid(8)
+    idx = lambda a, b, c: (a * 8 + b) * 8 + c
+    chosen = [idx(a, b, c) for a in (0, 7) for b in (0, 7) for c in (0, 7)]
+    for a in range(8):
+        for b in range(8):
+            c = (3 * a + 5 * b + 1) % 8           # a Latin-square style spread: every level of c for every a and b
+            chosen.append(idx(a, b, c))
+    chosen = list(dict.fromkeys(chosen))[:64]
+    return [pts[i] for i in chosen], chosen
+
+
+def test_theta_grid_meets_the_north_star_tolerance():
+    """BASELINE configs[4] at its stated bar (north star: 'log-lik match <= 1e-5 rel'), on 64
+    stratified points of the 512-point lattice incl. all 8 corners, N = 8192, d = 256, V factor reused
+    as the grid driver does.
+
+    The all-fp32 instance misses the bar on part of the lattice (2.8e-5 at corner 448; measured with
+    scripts/dev_fp32_err.py: rounding K~, V, m to fp32 moves the loss by 1e-8 -- it is the fp32
+    ARITHMETIC of the factorisations, log|K~| off by +0.5 .. +1.7, that does it), so the configuration
+    runs in the mixed mode: kernel build, both Cholesky factorisations and every scalar of the loss in
+    fp64, the N^3-heavy gradient products (T, Q, W, pull-back) in fp32.  Asserted here: mixed mode
+    loss <= 1e-5 (measured ~1e-8), gradients <= 1e-3 of the largest component (the north star states
+    no gradient tolerance); all-fp32 loss <= 5e-5 as a regression bound, not a claim of the bar."""
+    from gaussian_processes_amd.engine import GPFitEngine
+    dev = torch.device("cuda:0")
+    N, d = 8192, 256
+    grid, X, r, m, V = case(N, d, dev)
+    points, chosen = stratified_lattice_points()
+    assert len(points) == 64 and {0, 7, 56, 63, 448, 455, 504, 511} <= set(chosen)
+    eng = GPFitEngine(N, d)
+
+    def sweep(Xs, rs, ms, Vs, **kw):
+        rows = []
+        for i, th in enumerate(points):
+            o = eng.fit_eval(th, LOWER, UPPER, grid, Xs, rs, ms, Vs, LOGA, LAM0, want_vectors=False, reuse_V=i > 0, **kw)
+            rows.append([o["loss"]] + [o["grad"][k] for k in KEYS])
+        return np.array(rows)
+
+    ref = sweep(X, r, m, V)
+    mixed = sweep(X, r, m, V, grad_precision="f32")
+    all32 = sweep(*(t.to(torch.float32) for t in (X, r, m, V)))
+    eng.close()
+    for name, got, loss_tol in (("mixed", mixed, 1e-5), ("all-fp32", all32, 5e-5)):
+        loss_dev = np.abs(got[:, 0] - ref[:, 0]) / np.abs(ref[:, 0])
+        grad_dev = np.abs(got[:, 1:] - ref[:, 1:]).max(1) / np.abs(ref[:, 1:]).max(1)
+        print(f"{name} vs fp64 over 64 lattice points: loss max {loss_dev.max():.2e} (point {chosen[int(loss_dev.argmax())]}), "
+              f"median {np.median(loss_dev):.2e}; grad max {grad_dev.max():.2e}")
+        assert loss_dev.max() <= loss_tol, (name, loss_dev.max(), chosen[int(loss_dev.argmax())])
+        assert grad_dev.max() <= 1e-3, (name, grad_dev.max())
+
+
+def test_mixed_precision_small_and_ragged():
+    """The mixed mode on sizes with padding (N not a multiple of 128) and a rectangular pixel grid:
+    the loss and its parts are the fp64 ones bit for bit (same kernels), gradients within 1e-3."""
+    from gaussian_processes_amd.engine import GPFitEngine
+    dev = torch.device("cuda:0")
+    for N, d in ((200, 16), (1000, 128), (2048, 256)):
+        grid, X, r, m, V = case(N, d, dev)
+        eng = GPFitEngine(N, d)
+        th1 = syn.theta_eval()
+        a = eng.fit_eval(th1, LOWER, UPPER, grid, X, r, m, V, LOGA, LAM0)
+        b = eng.fit_eval(th1, LOWER, UPPER, grid, X, r, m, V, LOGA, LAM0, grad_precision="f32")
+        c2 = eng.fit_eval(th1, LOWER, UPPER, grid, X, r, m, V, LOGA, LAM0, grad_precision="f32", reuse_V=True)
+        eng.close()
+        assert a["loglik"] == b["loglik"] and a["logdet_K"] == b["logdet_K"] and a["logdet_V"] == b["logdet_V"]
+        assert abs(a["loss"] - b["loss"]) <= 1e-7 * abs(a["loss"])          # tr(K~^-1 V) comes from the fp32 T
+        ga = np.array([a["grad"][k] for k in KEYS])
+        for o in (b, c2):
+            gb = np.array([o["grad"][k] for k in KEYS])
+            assert np.abs(ga - gb).max() <= 1e-3 * np.abs(ga).max(), (N, ga, gb)
+        assert b["loss"] == c2["loss"]
 
 
 def test_fp32_rejects_mixed_dtypes():
