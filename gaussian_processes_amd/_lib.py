@@ -28,6 +28,7 @@ _SIGS = {
     "gpfit_fit_eval": (i32, [vp, vp, pd, pd, pd, i32, i32, vp, i64, i64, vp, vp, vp, i64, f64, f64, i32, pd,
                              vp, vp, vp]),
     "gpfit_potrf": (i32, [vp, vp, vp, i64, i64, vp, i64, vp, i64, pd, ctypes.POINTER(i32)]),
+    "gpfit_potrf_append": (i32, [vp, vp, vp, i64, vp, i64, i64, vp, pd, ctypes.POINTER(i32)]),
     "gpfit_estep": (i32, [vp, vp, vp, i64, i64, vp, vp, vp, f64, vp, vp, i64]),
     "gpfit_fparam_eval": (i32, [vp, vp, vp, vp, vp, i64, f64, i32, f64, vp, pd]),
     "gpfit_set_profile": (i32, [vp, i32]),

@@ -25,7 +25,102 @@ static int gemm_full(hipStream_t s, int ak, int bk, int M, int N, int K, double 
   return launch_gemm(g, s);
 }
 
+namespace {
+// y_i = sum_{j <= i} M[i][j] x_j for a lower-triangular row-major M (one wave per row)
+__global__ __launch_bounds__(256) void append_trmv_kernel(const double* __restrict__ M, int64_t ld, int n,
+                                                           const double* __restrict__ x, double* __restrict__ y) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= n) return;
+  double acc = 0.0;
+  for (int j = lane; j <= row; j += 64) acc += M[(int64_t)row * ld + j] * x[j];
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o);
+  if (lane == 0) y[row] = acc;
+}
+// w_j = sum_{i >= j} M[i][j] l_i (a 64-column strip per workgroup, rows walked in four interleaved
+// groups, summed in a fixed order: deterministic); also out[0] = l . l from workgroup 0
+__global__ __launch_bounds__(256) void append_trmv_t_kernel(const double* __restrict__ M, int64_t ld, int n,
+                                                             const double* __restrict__ l, double* __restrict__ w,
+                                                             double* __restrict__ out) {
+  __shared__ double part[4][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), g = threadIdx.x >> 6;
+  double acc = 0.0;
+  if (c < n)
+    for (int i = c + g; i < n; i += 4) acc += M[(int64_t)i * ld + c] * l[i];
+  part[g][threadIdx.x & 63] = acc;
+  __syncthreads();
+  if (g == 0 && c < n) w[c] = part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x];
+  if (blockIdx.x == 0) {
+    __shared__ double red[256];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) s += l[i] * l[i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+      if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = red[0];
+  }
+}
+// row n of both factors: L[n][:] = (l, lambda), Linv[n][:] = (-w / lambda, 1 / lambda); column n zeroed above
+__global__ __launch_bounds__(256) void append_write_kernel(double* __restrict__ L, int64_t ldl, double* __restrict__ Li,
+                                                            int64_t ldi, int n, const double* __restrict__ l,
+                                                            const double* __restrict__ w, const double* __restrict__ kcol,
+                                                            double* __restrict__ out, int* __restrict__ info) {
+  const double p = kcol[n] - out[0];           // Schur complement of the new diagonal entry
+  const bool bad = !(p > 0.0);
+  const double lam = bad ? 1.0 : sqrt(p);
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j == 0) {
+    out[1] = lam;
+    if (bad) atomicCAS(info, 0, n + 1);
+  }
+  if (j < n) {
+    L[(int64_t)n * ldl + j] = l[j];
+    Li[(int64_t)n * ldi + j] = -w[j] / lam;
+    L[(int64_t)j * ldl + n] = 0.0;
+    Li[(int64_t)j * ldi + n] = 0.0;
+  } else if (j == n) {
+    L[(int64_t)n * ldl + n] = lam;
+    Li[(int64_t)n * ldi + n] = 1.0 / lam;
+  }
+}
+}  // namespace
+
 extern "C" {
+
+int gpfit_potrf_append(gpfit_ctx* c, void* stream, double* L, int64_t ldl, double* Linv, int64_t ldi, int64_t n,
+                       const double* kcol, double* logdet_inout_host, int* info_host) {
+  if (!c || !L || !Linv || !kcol || n <= 0 || ldl <= n || ldi <= n) {
+    set_error("gpfit_potrf_append: bad argument (the factors need room for row and column n: ld > n)");
+    return -3;
+  }
+  GP_CTX_ENTER(c, "gpfit_potrf_append");
+  hipStream_t s = (hipStream_t)stream;
+  if (n + 1 > c->np_cap) {
+    set_error("gpfit_potrf_append: matrix larger than the context capacity");
+    return -3;
+  }
+  const int ni = (int)n;
+  double* l = c->yv;       // L^-1 k
+  double* w = c->bv;       // L^-T l
+  GP_HIP(hipMemsetAsync(c->info, 0, 4 * sizeof(int), s));
+  hipLaunchKernelGGL(append_trmv_kernel, dim3((ni + 3) / 4), dim3(256), 0, s, Linv, ldi, ni, kcol, l);
+  hipLaunchKernelGGL(append_trmv_t_kernel, dim3((ni + 63) / 64), dim3(256), 0, s, Linv, ldi, ni, l, w, c->scal + 48);
+  hipLaunchKernelGGL(append_write_kernel, dim3((ni + 256) / 256), dim3(256), 0, s, L, ldl, Linv, ldi, ni, l, w, kcol,
+                     c->scal + 48, c->info);
+  GP_HIP(hipGetLastError());
+  GP_HIP(hipMemcpyAsync(c->scal_host + 48, c->scal + 48, 2 * sizeof(double), hipMemcpyDeviceToHost, s));
+  GP_HIP(hipMemcpyAsync(c->info_host, c->info, 4 * sizeof(int), hipMemcpyDeviceToHost, s));
+  GP_HIP(hipStreamSynchronize(s));
+  if (info_host) *info_host = c->info_host[0];
+  if (c->info_host[0] != 0) {
+    set_error("gpfit_potrf_append: the extended matrix is not positive definite");
+    return c->info_host[0];
+  }
+  if (logdet_inout_host) *logdet_inout_host += 2.0 * std::log(c->scal_host[49]);
+  return 0;
+}
 
 int gpfit_potrf(gpfit_ctx* c, void* stream, const double* A, int64_t lda, int64_t n, double* L, int64_t ldl,
                 double* Linv, int64_t ldi, double* logdet_host, int* info_host) {

@@ -269,6 +269,32 @@ def cholesky(M, want_inverse=False):
     return L, Li, float(logdet.value), int(info.value)
 
 
+def cholesky_append(L, Linv, kcol, logdet=0.0):
+    """Factor of ``[[K, k], [k^T, kappa]]`` from the factor of K in O(n^2) (``gpfit_potrf_append``):
+    ``L``, ``Linv`` are (n+1) x (n+1) device tensors whose leading n x n blocks hold the factor of K and
+    its inverse (what ``cholesky(K, want_inverse=True)`` returned, embedded); ``kcol`` the n+1 entries of
+    the new last column.  Row n of both is written in place; returns ``(logdet_new, info)``.  The closed
+    loop of the reference's one_cell_active_training.ipynb adds one stimulus per iteration
+    (:1889-1891): with this the refit's factorisation of K~ costs a row, not an N^3 / 3."""
+    lib = _lib.load()
+    n = L.shape[0] - 1
+    if L.shape != (n + 1, n + 1) or Linv.shape != (n + 1, n + 1) or not (L.is_cuda and Linv.is_cuda):
+        raise ValueError("cholesky_append: L and Linv must be (n+1) x (n+1) device tensors")
+    if L.dtype != TORCH_DTYPE or Linv.dtype != TORCH_DTYPE or L.stride(1) != 1 or Linv.stride(1) != 1:
+        raise ValueError("cholesky_append: L and Linv must be row-major float64")
+    kcol = _cu(kcol).reshape(-1)
+    if kcol.shape[0] != n + 1:
+        raise ValueError("cholesky_append: kcol must hold n + 1 entries")
+    eng = get_engine(n + 1, 1)
+    ld = ctypes.c_double(float(logdet))
+    info = ctypes.c_int()
+    rc = lib.gpfit_potrf_append(eng._ctx, _stream(), L.data_ptr(), L.stride(0), Linv.data_ptr(), Linv.stride(0), n,
+                                kcol.data_ptr(), ctypes.byref(ld), ctypes.byref(info))
+    if rc < 0:
+        _lib.check(rc, "gpfit_potrf_append")
+    return float(ld.value), int(info.value)
+
+
 def spd_inverse(M):
     """M^-1 = L^-T L^-1 for a symmetric positive definite matrix (replaces the LU
     ``torch.linalg.solve(M, I)`` of utils.py:2067)."""

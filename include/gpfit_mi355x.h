@@ -161,6 +161,18 @@ int gpfit_grad_pullback(gpfit_ctx* ctx, void* stream, const double* theta, int n
 int gpfit_potrf(gpfit_ctx* ctx, void* stream, const double* A, int64_t lda, int64_t n, double* L, int64_t ldl,
                 double* Linv, int64_t ldi, double* logdet_host, int* info_host);
 
+/* Rank-1 append to a Cholesky factorisation: given L and L^-1 of the n x n matrix K (device, row-major,
+ * leading dimensions > n so that row and column n exist) and kcol[0..n] = the new last column of
+ * K' = [K k; k^T kappa] (device), writes row n of both factors in place,
+ *   L'[n][:] = (l^T, lambda),  L'^-1[n][:] = (-(L^-T l)^T / lambda, 1 / lambda),  l = L^-1 k,
+ *   lambda = sqrt(kappa - l.l),
+ * zeroes column n above the diagonal and adds 2 log(lambda) to *logdet_inout_host.  O(n^2) instead of
+ * the O(n^3) refactorisation: the closed loop of one_cell_active_training.ipynb appends one stimulus
+ * per iteration and updates its kernel matrices 'by their latest column' (:1889-1891).  Synchronises.
+ * Returns 0, or n + 1 (LAPACK info) when the Schur complement kappa - l.l is not positive. */
+int gpfit_potrf_append(gpfit_ctx* ctx, void* stream, double* L, int64_t ldl, double* Linv, int64_t ldi, int64_t n,
+                       const double* kcol, double* logdet_inout_host, int* info_host);
+
 /* E-step Newton update of q(lambda~) = N(m, V) (Estep, alpha = 1 branch, utils.py:1420-1439) in
  * the original basis (a = I): with s = A sqrt(f), M = I + S K~ S = L_M L_M^T, T = L_M^-1 S K~:
  *   V_new = K~ - T^T T,  m_new = V_new (A^2 f o m + A (r - f)).

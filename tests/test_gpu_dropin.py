@@ -514,6 +514,51 @@ def test_pending_evaluation_blocks_other_entry_points():
     eng.close()
 
 
+def test_cholesky_rank1_append(gp):
+    """the closed loop appends one stimulus per iteration and updates K~ 'by its latest
+    column' (one_cell_active_training.ipynb:1889-1891).  gpfit_potrf_append extends L and L^-1 by that
+    column in O(n^2).  (a) on the real reference's own matrices of fixture G9 (K_tilde_new 49 x 49, whose
+    leading 48 x 48 block is the K~ before the append): the appended factor equals the
+    refactorisation to 1e-12; (b) five successive appends at n = 1000 (ragged against every tile size),
+    log-det carried along; (c) a column that makes the matrix indefinite reports LAPACK info = n + 1."""
+    g = load_golden("g9_active_step.npz")
+    Kn = T(g["K_tilde_new"])
+    n = Kn.shape[0] - 1
+    L0, Li0, logdet0, info = gp.cholesky(Kn[:n, :n].contiguous(), want_inverse=True)
+    assert info == 0
+    L = torch.zeros((n + 1, n + 1), dtype=torch.float64, device="cuda"); Li = torch.zeros_like(L)
+    L[:n, :n], Li[:n, :n] = L0, Li0
+    logdet, info = gp.cholesky_append(L, Li, Kn[:, n].contiguous(), logdet0)
+    Lref = torch.linalg.cholesky(Kn)
+    assert info == 0
+    assert relerr(L.cpu().numpy(), Lref.cpu().numpy()) < 1e-12
+    assert relerr((Li @ Lref).cpu().numpy(), np.eye(n + 1)) < 1e-11
+    assert abs(logdet - float(torch.logdet(Kn))) < 1e-11 * abs(logdet)
+    # (b) successive appends
+    gen = torch.Generator().manual_seed(4)
+    n0, extra = 1000, 5
+    M = torch.randn(n0 + extra, n0 + extra, dtype=torch.float64, generator=gen)
+    S = (M @ M.T + (n0 + extra) * torch.eye(n0 + extra, dtype=torch.float64)).cuda()
+    L0, Li0, logdet, info = gp.cholesky(S[:n0, :n0].contiguous(), want_inverse=True)
+    cap = n0 + extra
+    Lc = torch.zeros((cap, cap), dtype=torch.float64, device="cuda"); Lic = torch.zeros_like(Lc)
+    Lc[:n0, :n0], Lic[:n0, :n0] = L0, Li0
+    for k in range(extra):
+        nn = n0 + k
+        logdet, info = gp.cholesky_append(Lc[:nn + 1, :nn + 1], Lic[:nn + 1, :nn + 1], S[:nn + 1, nn].contiguous(), logdet)
+        assert info == 0
+    Lref = torch.linalg.cholesky(S)
+    assert relerr(Lc.cpu().numpy(), Lref.cpu().numpy()) < 1e-12
+    assert relerr((Lic @ Lref).cpu().numpy(), np.eye(cap)) < 1e-10
+    assert abs(logdet - float(torch.logdet(S))) < 1e-11 * abs(logdet)
+    # (c) indefinite extension
+    bad = S[:n0 + 1, n0].clone(); bad[n0] = -1.0
+    Lb = torch.zeros((n0 + 1, n0 + 1), dtype=torch.float64, device="cuda"); Lib = torch.zeros_like(Lb)
+    Lb[:n0, :n0], Lib[:n0, :n0] = L0, Li0
+    _, info = gp.cholesky_append(Lb, Lib, bad, 0.0)
+    assert info == n0 + 1
+
+
 def test_rank_decision_without_eigh(gp):
     """SURVEY 8 f-1 (second half): the reference's truncation rule (utils.py:1683) decided from the
     Cholesky factor instead of an eigendecomposition.  (a) well-conditioned K~ with a tiny tolerance:
