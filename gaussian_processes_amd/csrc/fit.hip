@@ -619,6 +619,172 @@ static int grad_pullback_impl(gpfit_ctx* c, void* stream, const double* theta, i
   return 0;
 }
 
+// Truncated-rank (B-projected) M-step closure with the inducing set = the training set
+// (utils.py:2030-2099 with n < n_tilde = n_t), fused: kernel build, projection on the kept
+// eigen-directions B, Cholesky of the n x n matrices, moments / likelihood / KL, the n x n and N x n
+// adjoints of the loss, their lift W = (B G_K~b + G_Kb) B^T and the pull-back to the metric, all on
+// the device in one call (the algebra of utils._closure_projected).  Every
+// N x n matrix lives zero-padded to nb = ceil(n / 128) 128 columns in one of the context's N x N
+// work matrices; the n x n ones carry the identity on their padding (log-determinants and solves
+// are unaffected, the padding of G_K~b cancels to zero).
+static int fit_eval_projected_impl(gpfit_ctx* c, void* stream, const double* theta, const double* lower,
+                                   const double* upper, int n_rows, int n_cols, const double* X, int64_t ldx, int64_t N,
+                                   const double* r, const double* B, int64_t ldb, int64_t n_kept, const double* m_b,
+                                   const double* V_b, int64_t ldvb, double logA, double lambda0, double* out_host) {
+  using R = double;
+  if (!c || !theta || !X || !r || !B || !m_b || !V_b || !out_host || N <= 0 || n_kept <= 0 || n_kept > N) {
+    set_error("gpfit_fit_eval_projected: bad argument");
+    return -3;
+  }
+  GP_CTX_ENTER(c, "gpfit_fit_eval_projected");
+  const double inf = std::numeric_limits<double>::infinity();
+  if (lower && upper && check_limits(theta, lower, upper) != 0) {
+    out_host[0] = inf;
+    out_host[1] = out_host[2] = std::numeric_limits<double>::quiet_NaN();
+    for (int i = 0; i < 6; ++i) out_host[3 + i] = inf;
+    return -2;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  const int n = (int)N, np = (int)round_up(N, TILE), nk = (int)n_kept, nb = (int)round_up(n_kept, TILE);
+  const int dfull = n_rows * n_cols;
+  if (np > c->np_cap || dfull > c->dfull_cap) {
+    set_error("gpfit_fit_eval_projected: problem larger than the context capacity");
+    return -3;
+  }
+  const int d = compute_mask(theta, n_rows, n_cols, nullptr, c->pix_host);
+  const int dp = (int)round_up(d, 32);
+  if (d <= 0 || dp > c->dp_cap) {
+    set_error("gpfit_fit_eval_projected: masked pixel count is zero or exceeds the context capacity");
+    return -3;
+  }
+  const Theta th = make_theta(theta);
+  const double s0sq = th.sigma0 * th.sigma0, A = std::exp(logA);
+  const int64_t ld = np, lb = nb;
+  c->lv_valid = false; c->lv32_valid = false;
+  c->side_ev_next[0] = c->side_ev_next[1] = 0;
+  g_main_sk_ws = c->sk_ws[0];
+  double *Kt = c->Kbuf, *Bp = c->Lbuf, *Kb = c->Libuf, *aV = c->Tbuf, *Ga = c->Zbuf, *GaKi = c->Tmp, *W = c->Wbuf;
+  double *S1 = c->Vbuf, *S2 = c->LVbuf, *S3 = c->LiVbuf, *S4 = c->TmpV;   // n x n scratch (leading dimension nb)
+  double *mbp = c->mpad, *bvec = c->yv, *gm = c->dq1, *gv = c->dq2;
+  GP_HIP(hipMemsetAsync(c->info, 0, 4 * sizeof(int), s));
+  GP_HIP(hipMemcpyAsync(c->pix, c->pix_host, (size_t)d * sizeof(int), hipMemcpyHostToDevice, s));
+  // ---- auxiliary stream: log|V_b| (:1326) on its own copy of V_b, in four work matrices the main
+  //      stream does not touch before the join (Abuf, Wbuf, Zbuf, Tmp)
+  GP_HIP(hipEventRecord(c->ev_fork, s));
+  GP_HIP(hipStreamWaitEvent(c->aux, c->ev_fork, 0));
+  GP_TRY(launch_pack_lower(V_b, ldvb, nk, c->Abuf, lb, nb, c->aux));
+  {
+    CholBufsT<R> bv{c->Abuf, c->Wbuf, c->Zbuf, c->Tmp, lb, c->info + 1, 1, c->sk_ws[1]};
+    GP_TRY(potrf_rec<R>(bv, 0, nb, 0, c->aux));
+  }
+  GP_TRY(launch_logdet(c->Wbuf, lb, nk, c->scal + 40, c->aux));
+  GP_HIP(hipEventRecord(c->ev_join, c->aux));
+  // ---- kernel build (as the full-rank unit): C, X masked, K~ (lower tiles -> mirrored), cos, Kvec, q
+  GP_TRY(launch_localker<R>(th, c->pix, d, dp, n_rows, n_cols, c->Cmat, dp, nullptr, s));
+  GP_TRY(launch_gather(X, ldx, n, c->pix, d, dp, np, c->Xt, ld, c->Xm, dp, s));
+  GP_TRY(gemm<R>(s, 1, 1, dp, np, dp, 1.0, c->Cmat, dp, c->Xt, ld, 0.0, c->XCt, ld, 0, 0, 0));
+  GP_TRY(launch_qvec(c->Xt, c->XCt, ld, dp, n, np, s0sq, c->Kvec, c->q, s));
+  {
+    GramArgsT<R> g{};
+    g.XCt = c->XCt; g.Xt = c->Xt; g.q1 = c->q; g.q2 = c->q; g.Kout = Kt; g.Cos = c->Cos;
+    g.ld1 = ld; g.ld2 = ld; g.ldk = ld; g.np1 = np; g.np2 = np; g.nv1 = n; g.nv2 = n; g.Kd = dp;
+    g.s0sq = s0sq; g.lower = 1; g.pad_identity = 1;
+    GP_TRY(launch_gram(g, s));
+  }
+  GP_TRY(launch_symmetrize(Kt, ld, np, s));
+  // ---- projection (utils.py:2047-2049): K_b = K~ B, K~_b = sym(B^T K_b)
+  GP_TRY(launch_pad_copy(B, ldb, n, nk, Bp, lb, np, nb, s));
+  GP_HIP(hipMemsetAsync(mbp, 0, (size_t)np * sizeof(double), s));
+  GP_HIP(hipMemcpyAsync(mbp, m_b, (size_t)nk * sizeof(double), hipMemcpyDeviceToDevice, s));
+  GP_TRY(gemm<R>(s, 0, 1, np, nb, np, 1.0, Kt, ld, Bp, lb, 0.0, Kb, lb, 0, 0, 0));
+  GP_TRY(gemm<R>(s, 1, 1, nb, nb, np, 1.0, Bp, lb, Kb, lb, 0.0, S4, lb, 0, 0, 0));
+  GP_TRY(launch_symmetrize_avg(S4, lb, nk, s));                                             // :2048
+  GP_TRY(launch_pack_lower(S4, lb, nk, S1, lb, nb, s));
+  {
+    CholBufsT<R> bk{S1, S2, S3, S4, lb, c->info + 0, 0, c->sk_ws[0]};
+    GP_TRY(potrf_rec<R>(bk, 0, nb, 1, s));                                                    // K~_b = L L^T, L^-1  (:2067)
+  }
+  GP_TRY(launch_logdet(S2, lb, nk, c->scal + 3, s));
+  // K~_b^-1 = L^-T L^-1 (lower tiles, mirrored)
+  GP_TRY(gemm<R>(s, 1, 1, nb, nb, nb, 1.0, S3, lb, S3, lb, 0.0, S1, lb, 1, 2, 1));
+  GP_TRY(launch_symmetrize(S1, lb, nb, s));
+  double* Ki = S1;
+  // V_b padded (identity on the padding), a V = B V_b, K~_b^-1 V_b and its trace, K~_b^-1 V_b K~_b^-1
+  GP_TRY(launch_pack_lower(V_b, ldvb, nk, S2, lb, nb, s));
+  GP_TRY(launch_symmetrize(S2, lb, nb, s));
+  GP_TRY(gemm<R>(s, 0, 1, np, nb, nb, 1.0, Bp, lb, S2, lb, 0.0, aV, lb, 0, 0, 0));
+  GP_TRY(gemm<R>(s, 0, 1, nb, nb, nb, 1.0, Ki, lb, S2, lb, 0.0, S3, lb, 0, 0, 0));
+  GP_TRY(launch_proj_trace(S3, lb, nk, c->scal + 5, s));                                     // tr(K~_b^-1 V_b)
+  GP_TRY(gemm<R>(s, 0, 1, nb, nb, nb, 1.0, S3, lb, Ki, lb, 0.0, S4, lb, 0, 0, 0));            // P1
+  GP_TRY(launch_symv_lower(Ki, lb, nb, mbp, bvec, s));                                        // b = K~_b^-1 m_b
+  GP_TRY(launch_dot(mbp, bvec, nb, c->scal + 6, s));
+  // ---- moments, rate, likelihood pieces (:1090, 1101, 1138, 1243) and the per-point adjoints
+  GP_TRY(launch_proj_moments(Bp, Kb, aV, lb, nb, mbp, c->Kvec, r, n, A, lambda0, c->lam_m, c->lam_var, c->fvec, gm, gv,
+                             c->upart, c->scal + 0, s));
+  // ---- adjoints (utils._closure_projected): G_a, G_Kb, G_K~b, W
+  GP_HIP(hipStreamWaitEvent(s, c->ev_join, 0));   // the V_b chain is done with Abuf, Wbuf, Zbuf, Tmp
+  GP_TRY(launch_proj_ga(Kb, aV, lb, nb, n, np, gm, gv, mbp, Ga, s));
+  GP_TRY(gemm<R>(s, 0, 1, np, nb, nb, 1.0, Ga, lb, Ki, lb, 0.0, GaKi, lb, 0, 0, 0));
+  GP_TRY(gemm<R>(s, 1, 1, nb, nb, np, 1.0, Bp, lb, GaKi, lb, 0.0, c->Abuf, lb, 0, 0, 0));    // P2 = B^T G_a K~_b^-1
+  GP_TRY(launch_proj_gktb(Ki, S4, c->Abuf, lb, nb, bvec, S3, s));                            // G_K~b
+  GP_TRY(launch_proj_gkb(Bp, lb, nb, n, np, gv, GaKi, s));                                   // G_Kb (in place)
+  GP_TRY(gemm<R>(s, 0, 1, np, nb, nb, 1.0, Bp, lb, S3, lb, 1.0, GaKi, lb, 0, 0, 0));          // + B G_K~b
+  GP_TRY(gemm<R>(s, 0, 0, np, np, nb, 1.0, GaKi, lb, Bp, lb, 0.0, W, ld, 0, 0, 0));           // W = (.) B^T
+  GP_TRY(launch_symmetrize_avg(W, ld, np, s));
+  // ---- pull-back of <W, dK~_p> + <gvec, dKvec_p> to the metric (as gpfit_grad_pullback; gvec = -g_v)
+  GP_HIP(hipMemsetAsync(c->bv, 0, (size_t)np * sizeof(R), s));
+  GP_HIP(hipMemsetAsync(c->wl, 0, (size_t)np * sizeof(R), s));
+  GP_TRY(launch_scale_copy<R>(c->wl, gv, n, 1.0, s));
+  GP_TRY(launch_adjoint(W, c->Cos, ld, c->bv, c->q, n, np, c->Abuf, c->upart, c->vpart, c->sumA_part, s));
+  const int t64 = np / 64;
+  GP_TRY(launch_adjoint_reduce(c->upart, c->vpart, c->sumA_part, t64, t64 * (t64 + 1) / 2, c->q, c->wl, n, np, c->tvec,
+                               c->rpad, c->scal + 7, s));
+  GP_TRY(gemm<R>(s, 1, 1, np, dp, np, 1.0, c->Abuf, ld, c->Xm, dp, 0.0, c->Ybuf, dp, 0, 0, 0));
+  GP_TRY(launch_rowscale_add(c->Ybuf, dp, c->Xm, dp, c->tvec, np, dp, s));
+  {
+    GemmArgsT<R> g{};
+    g.A = c->Xm; g.B = c->Ybuf; g.C = c->Mpart;
+    g.lda = dp; g.ldb = dp; g.ldc = dp;
+    g.M = dp; g.N = dp; g.K = np;
+    g.alpha = 1.0; g.beta = 0.0; g.a_kmajor = 1; g.b_kmajor = 1;
+    g.batch = 1; g.split_k = c->split_k_M; g.sC = (int64_t)dp * dp;
+    GP_TRY(launch_gemm(g, s));
+    GP_TRY(launch_reduce_slices(c->Mpart, (int64_t)dp * dp, c->split_k_M, c->Mmat, (int64_t)dp * dp, s));
+  }
+  GP_TRY(launch_metric_contract(th, c->pix, d, n_rows, n_cols, c->Cmat, dp, c->Mmat, dp, c->scal + 10, s));
+  GP_HIP(hipMemcpyAsync(c->scal_host, c->scal, 64 * sizeof(double), hipMemcpyDeviceToHost, s));
+  GP_HIP(hipMemcpyAsync(c->info_host, c->info, 4 * sizeof(int), hipMemcpyDeviceToHost, s));
+  GP_HIP(hipStreamSynchronize(s));
+  const double* sc = c->scal_host;
+  const double loglik = A * sc[0] + lambda0 * sc[1] - sc[2];                                 // :1243
+  const double KL = -0.5 * sc[40] + 0.5 * sc[3] + 0.5 * sc[6] + 0.5 * sc[5];                  // :1326
+  out_host[0] = -(loglik - KL);
+  out_host[1] = loglik;
+  out_host[2] = KL;
+  out_host[3] = th.sigma0 * (2.0 * sc[9] + 2.0 * sc[7]) - 2.0 * th.sigma0 * sc[8];
+  out_host[4] = sc[13];
+  out_host[5] = sc[14];
+  out_host[6] = sc[11];
+  out_host[7] = sc[12];
+  out_host[8] = sc[10];
+  out_host[9] = sc[3];
+  out_host[10] = sc[40];
+  out_host[11] = sc[5];
+  out_host[12] = sc[6];
+  out_host[13] = (double)d;
+  out_host[14] = (double)c->info_host[0];
+  out_host[15] = (double)c->info_host[1];
+  if (c->info_host[0] != 0) {
+    set_error("gpfit_fit_eval_projected: Cholesky of the projected K_tilde failed (non-positive pivot)");
+    return c->info_host[0];
+  }
+  if (c->info_host[1] != 0) {
+    set_error("gpfit_fit_eval_projected: Cholesky of V_b failed (non-positive pivot)");
+    return c->info_host[1];
+  }
+  return 0;
+}
+
 // Wait for the evaluation enqueued on this context and assemble its 16 host scalars.
 int fit_eval_finish(gpfit_ctx* c, double* out_host) {
   if (!c || !out_host || !c->pend.active) {
@@ -696,6 +862,14 @@ int gpfit_fit_eval_f32(gpfit_ctx* c, void* stream, const double* theta, const do
 }
 
 int gpfit_fit_eval_finish(gpfit_ctx* c, double* out_host) { return fit_eval_finish(c, out_host); }
+
+int gpfit_fit_eval_projected(gpfit_ctx* c, void* stream, const double* theta, const double* lower, const double* upper,
+                             int n_rows, int n_cols, const double* X, int64_t ldx, int64_t N, const double* r,
+                             const double* B, int64_t ldb, int64_t n_kept, const double* m_b, const double* V_b,
+                             int64_t ldvb, double logA, double lambda0, double* out_host) {
+  return fit_eval_projected_impl(c, stream, theta, lower, upper, n_rows, n_cols, X, ldx, N, r, B, ldb, n_kept, m_b, V_b,
+                                 ldvb, logA, lambda0, out_host);
+}
 
 int gpfit_grad_pullback(gpfit_ctx* c, void* stream, const double* theta, int n_rows, int n_cols, const double* X,
                         int64_t ldx, int64_t N, const double* W, int64_t ldw, const double* gvec, double* out6) {

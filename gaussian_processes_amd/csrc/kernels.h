@@ -117,6 +117,17 @@ int launch_dk_metric(double* H, int64_t ldh, const double* Cos, int64_t ldc, con
                      const double* dq1, const double* dq2, int n1, int n2, hipStream_t s);
 int launch_fill(double* x, int64_t n, double v, hipStream_t s);
 
+// ---- projected.hip: element-wise pieces of the fused truncated-rank closure (gpfit_fit_eval_projected)
+int launch_proj_moments(const double* Bp, const double* Kb, const double* aV, int64_t ld, int nb, const double* mb,
+                        const double* Kvec, const double* r, int n, double A, double lambda0, double* lam_m,
+                        double* lam_var, double* f, double* gm, double* gv, double* part, double* out3, hipStream_t s);
+int launch_proj_ga(const double* Kb, const double* aV, int64_t ld, int nb, int n, int np, const double* gm,
+                   const double* gv, const double* mb, double* Ga, hipStream_t s);
+int launch_proj_gkb(const double* Bp, int64_t ld, int nb, int n, int np, const double* gv, double* GaKi, hipStream_t s);
+int launch_proj_gktb(const double* Ki, const double* P1, const double* P2, int64_t ld, int nb, const double* b, double* G,
+                     hipStream_t s);
+int launch_proj_trace(const double* A, int64_t lda, int n, double* out, hipStream_t s);
+
 // ---- E-step / factorisation / firing-rate helpers
 int launch_estep_prep(const double* f, const double* r, const double* m, int n, int np, double A, double* sv,
                       double* rhs, hipStream_t s);

@@ -765,6 +765,35 @@ def _closure_general(theta, lims, n_px_side, x, xtilde, r, B, m_b, V_b, f_params
 
 
 def _closure_projected(theta, lims, n_px_side, x, r, B, m_b, V_b, f_params):
+    """Truncated-rank M-step closure (utils.py:2030-2099 with n < n_tilde = n_t): ONE call of the fused
+    entry point ``gpfit_fit_eval_projected`` (kernel build, projection, the two n x n Cholesky
+    factorisations, moments / likelihood / KL, adjoints, lift and pull-back on the device).  When a
+    factorisation meets a non-positive pivot the reference's ``log_det`` would take its
+    eigen-fallback (utils.py:1279-1304): the step-by-step formulation below (``_closure_projected_steps``)
+    reproduces that and is used instead."""
+    lib = _lib.load()
+    lower, upper = lims
+    xc, rc, Bc, mc, Vc = _cu(x), _cu(r), _cu(B), _cu(m_b), _cu(V_b)
+    rows, cols = _grid(n_px_side)
+    N, nk = Bc.shape
+    eng = get_engine(N, xc.shape[1], rows * cols)
+    out = (ctypes.c_double * 16)()
+    rc_ = lib.gpfit_fit_eval_projected(eng._ctx, _stream(), _lib.darr(theta_vec(theta)),
+                                       _lib.darr([_scalar(lower[k]) for k in THETA_KEYS]),
+                                       _lib.darr([_scalar(upper[k]) for k in THETA_KEYS]), rows, cols,
+                                       xc.data_ptr(), xc.stride(0), N, rc.data_ptr(), Bc.data_ptr(), Bc.stride(0), nk,
+                                       mc.data_ptr(), Vc.data_ptr(), Vc.stride(0), _scalar(f_params['logA']),
+                                       _scalar(_lambda0_of(f_params)), out)
+    if rc_ == -2:
+        raise ValueError(_lib.last_error())
+    if rc_ < 0:
+        _lib.check(rc_, "gpfit_fit_eval_projected")
+    if rc_ == 0:
+        return out[0], {k: out[3 + i] for i, k in enumerate(THETA_KEYS)}
+    return _closure_projected_steps(theta, lims, n_px_side, x, r, B, m_b, V_b, f_params)
+
+
+def _closure_projected_steps(theta, lims, n_px_side, x, r, B, m_b, V_b, f_params):
     """Truncated-rank M-step closure (utils.py:2030-2099 with n < n_tilde = n_t, inducing set =
     training set) in adjoint form: the same loss as the reference's B-projected formulation, but
     instead of materialising the six dK~_p and projecting each of them (13 + 13 GEMMs of N x N x n),

@@ -152,6 +152,24 @@ int gpfit_grad_pullback(gpfit_ctx* ctx, void* stream, const double* theta, int n
                         const double* X, int64_t ldx, int64_t N, const double* W, int64_t ldw,
                         const double* gvec, double* out_host);
 
+/* Truncated-rank M-step closure, fused: the reference's B-projected closure (utils.py:2030-2099) in the
+ * regime its default EIGVAL_TOL produces at realistic sizes -- inducing set = training set, n_kept < N
+ * eigen-directions kept.  X[N][ldx] un-masked stimuli, r[N], B[N][ldb] the kept eigenvectors (orthonormal
+ * columns, utils.py:1685), m_b[n_kept], V_b[n_kept][ldvb], all device.  One call does the kernel build,
+ * the projections K_b = K~ B and K~_b = sym(B^T K_b), the Cholesky factorisations of K~_b and V_b, the
+ * moments / likelihood / KL of utils.py:1090-1326 with a = B (:2068), the adjoints of the loss with
+ * respect to K_b, K~_b and Kvec (da_p of :1114 included), their lift to the N x N adjoint
+ * W = (B G_K~b + G_Kb) B^T and its contraction with the analytic dK~_p / dKvec_p by the pull-back to
+ * the metric -- no dK, no N x N x 6 tensor, nothing computed by the host framework.
+ * out_host[16] as gpfit_fit_eval (9 log|K~_b|, 10 log|V_b|, 11 tr(K~_b^-1 V_b), 12 m_b^T K~_b^-1 m_b,
+ * 14 / 15 LAPACK info of the two factorisations).  Returns 0; -2 outside the hyperparameter box
+ * (infinite loss and gradients); > 0 when a factorisation meets a non-positive pivot (the caller then
+ * takes the reference's eigen-fallback of log_det, utils.py:1279-1304).  Synchronises. */
+int gpfit_fit_eval_projected(gpfit_ctx* ctx, void* stream, const double* theta, const double* lower,
+                             const double* upper, int n_rows, int n_cols, const double* X, int64_t ldx, int64_t N,
+                             const double* r, const double* B, int64_t ldb, int64_t n_kept, const double* m_b,
+                             const double* V_b, int64_t ldvb, double logA, double lambda0, double* out_host);
+
 /* Cholesky factorisation A = L L^T of a symmetric positive definite n x n matrix (lower
  * triangle read) by the recursive MFMA algorithm; replaces torch.linalg.cholesky in log_det
  * (utils.py:1275) and, through L^-1, the LU torch.linalg.solve(., I) of the closure

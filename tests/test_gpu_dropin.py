@@ -152,6 +152,48 @@ def test_sparse_adjoint_closure(gp):
     assert np.abs(a1 - a2).max() <= 1e-7 * np.abs(a1).max()
 
 
+def test_fused_projected_closure_equals_step_by_step(gp):
+    """gpfit_fit_eval_projected (one call) against the step-by-step adjoint formulation it fuses, at
+    N = 1000 (ragged) with the reference's default tolerance: same loss to 1e-11, same gradients to
+    1e-9 -- and against the reference itself on the truncated fixture in the test above."""
+    N, d = 1000, 256
+    th = tth([syn.theta_eval()[k] for k in KEYS])
+    X = T(syn.stimuli(N, d))
+    r_np, m_np = syn.cell_inputs(N)
+    r, m = T(r_np), T(m_np)
+    C, mask = gp.localker(th, UPPER, LOWER, 16)
+    Kt = gp.acosker(th, X[:, mask].contiguous(), X[:, mask].contiguous(), C=C)
+    ev, evec = torch.linalg.eigh(Kt)
+    keep = ev > max(float(ev.max()) * 1e-4, 1e-4)
+    B = evec[:, keep].contiguous()
+    assert 16 < B.shape[1] < N and B.shape[1] % 128 != 0
+    m_b = gp.matmul(B, m, transA=True)
+    V_b = gp.matmul(B, gp.matmul(0.5 * Kt, B), transA=True)
+    V_b = (V_b + V_b.T) / 2
+    fp = {"logA": torch.tensor(np.log(0.2), dtype=torch.float64),
+          "lambda0": torch.tensor(syn.F_PARAMS["lambda0"], dtype=torch.float64)}
+    th2 = tth([syn.theta_eval()[k] * (1.01 if k == "Amp" else 1.0) for k in KEYS])
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        l1, g1 = gp._closure_projected_steps(th2, (LOWER, UPPER), 16, X, r, B, m_b, V_b, fp)
+        l2, g2 = gp._closure_projected(th2, (LOWER, UPPER), 16, X, r, B, m_b, V_b, fp)
+    assert abs(l1 - l2) <= 1e-11 * abs(l1)
+    a1, a2 = np.array([g1[k] for k in KEYS]), np.array([g2[k] for k in KEYS])
+    assert np.abs(a1 - a2).max() <= 1e-9 * np.abs(a1).max()
+    # outside the box: the reference's closure hands inf to L-BFGS; the drop-in closure raises like localker
+    bad = tth([syn.theta_eval()[k] for k in KEYS]); bad["Amp"] = torch.tensor(-1.0, dtype=torch.float64)
+    with pytest.raises(ValueError):
+        gp._closure_projected(bad, (LOWER, UPPER), 16, X, r, B, m_b, V_b, fp)
+    # a V_b that is not positive definite: the fused call reports it and the step-by-step fallback
+    # (reference's eigen-fallback of log_det) takes over -- same value as calling it directly
+    Vbad = V_b.clone(); Vbad[0, 0] = -1.0
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        lf, _ = gp._closure_projected(th2, (LOWER, UPPER), 16, X, r, B, m_b, Vbad, fp)
+        ls, _ = gp._closure_projected_steps(th2, (LOWER, UPPER), 16, X, r, B, m_b, Vbad, fp)
+    assert lf == ls
+
+
 def test_projected_adjoint_closure_matches_general_at_scale(gp):
     """Same two formulations against each other at N=1536, d=256 with the reference's default
     tolerance (a few hundred of 1536 directions kept)."""
