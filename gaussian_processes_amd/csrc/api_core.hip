@@ -38,7 +38,8 @@ int gpfit_dgemm_ex(void* stream, int a_kmajor, int b_kmajor, int M, int N, int K
   g.alpha = alpha; g.beta = beta;
   g.a_kmajor = a_kmajor; g.b_kmajor = b_kmajor;
   g.out_lower = out_lower; g.a_tri = a_tri; g.b_tri = b_tri;
-  g.batch = 1; g.split_k = 1; g.reverse = walk; g.tile = tile;
+  g.batch = 1; g.split_k = 1; g.reverse = walk & 15; g.tile = tile;
+  g.half_occ = (walk >> 4) & 1;  // bit 4: one workgroup per CU (a long GEMM that must leave room for latency-bound kernels)
   return gpfit::launch_gemm(g, (hipStream_t)stream);
 }
 

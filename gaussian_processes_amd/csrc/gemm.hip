@@ -167,6 +167,7 @@ static void launch_T(const GemmArgsT<R>& p, hipStream_t s) {
 template <typename R>
 int launch_gemm(const GemmArgsT<R>& a, hipStream_t s) {
   if (a.M <= 0 || a.N <= 0) return 0;
+  if (a.half_occ) return launch_gemm_plain(a, s);
   if (a.tile_limit == 0 && gemm_pick_tile(a) == TILE && a.batch <= 1) {
     if (a.reverse & 8) {
       const int rc = launch_gemm_xcd(a, s);    // XCD-aware data-parallel schedule (gemm_sched.hip)

@@ -44,7 +44,8 @@ int gpfit_dgemm(void* stream, int a_kmajor, int b_kmajor, int M, int N, int K, d
                 const double* A, int64_t lda, const double* B, int64_t ldb, double beta, double* C,
                 int64_t ldc, int out_lower, int a_tri, int b_tri);
 /* Same with the tuning knobs exposed: walk (bit 0: tile grid backwards, bit 1: column-major -- also
- * for the lower triangle of an out_lower launch --, bit 2: every tile walks k downwards)
+ * for the lower triangle of an out_lower launch --, bit 2: every tile walks k downwards, bit 3: XCD-aware
+ * macro-tile schedule for launches of >= 1536 tiles, bit 4: one workgroup per CU)
  * and tile (0 = automatic, or 128 / 64 / 32). */
 int gpfit_dgemm_ex(void* stream, int a_kmajor, int b_kmajor, int M, int N, int K, double alpha,
                    const double* A, int64_t lda, const double* B, int64_t ldb, double beta, double* C,
