@@ -1,15 +1,18 @@
-"""Turn the rocprofv3 / bench outputs of the last gpurun call (gpurun_out/) into the tracked profiles/r01_* files."""
+"""Turn the rocprofv3 / bench outputs of scripts/collect_profiles.sh <tag> (gpurun_out/<tag>_*) into the tracked profiles/<tag>_* files."""
 import collections, csv, glob, json, os, shutil, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 G, P = os.path.join(ROOT, "gpurun_out"), os.path.join(ROOT, "profiles")
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
-subprocess.check_call([sys.executable, os.path.join(ROOT, "scripts", "make_profile_summary.py"), tag, os.path.join(G, "kt"),
-                       os.path.join(G, "pmcf"), os.path.join(G, "pmcw")], stdout=subprocess.DEVNULL)
-shutil.copy(os.path.join(G, "bench_full.json"), os.path.join(P, f"{tag}_bench.json"))
-shutil.copy(os.path.join(G, "bench_f32.json"), os.path.join(P, f"{tag}_bench_f32.json"))
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+subprocess.check_call([sys.executable, os.path.join(ROOT, "scripts", "make_profile_summary.py"), tag, os.path.join(G, f"{tag}_kt"),
+                       os.path.join(G, f"{tag}_pmcf"), os.path.join(G, f"{tag}_pmcw")], stdout=subprocess.DEVNULL)
+shutil.copy(os.path.join(G, f"{tag}_bench_full.json"), os.path.join(P, f"{tag}_bench.json"))
+shutil.copy(os.path.join(G, f"{tag}_bench_f32.json"), os.path.join(P, f"{tag}_bench_f32.json"))
+for extra in ("bench_mixed.json", "size_sweep.jsonl", "whole_fits.log"):
+    if os.path.exists(os.path.join(G, f"{tag}_{extra}")):
+        shutil.copy(os.path.join(G, f"{tag}_{extra}"), os.path.join(P, f"{tag}_{extra}"))
 with open(os.path.join(P, f"{tag}_configs.jsonl"), "w") as o:
-    o.writelines(l for l in open(os.path.join(G, "configs.log")) if l.startswith("{"))
-f = max(glob.glob(os.path.join(G, "pmcm", "*", "*_counter_collection.csv")), key=os.path.getmtime)
+    o.writelines(l for l in open(os.path.join(G, f"{tag}_configs.jsonl")) if l.startswith("{"))
+f = max(glob.glob(os.path.join(G, f"{tag}_pmcm", "*", "*_counter_collection.csv")), key=os.path.getmtime)
 agg = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = collections.Counter()
 for r in csv.DictReader(open(f)):
     k = r["Kernel_Name"].split("(")[0]
