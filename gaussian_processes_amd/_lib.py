@@ -39,6 +39,8 @@ _SIGS = {
                                  vp, vp, vp]),
     "gpfit_fit_eval_finish": (i32, [vp, pd]),
     "gpfit_fit_eval_projected": (i32, [vp, vp, pd, pd, pd, i32, i32, vp, i64, i64, vp, vp, i64, i64, vp, vp, i64, f64, f64, pd]),
+    "gpfit_fit_eval_sparse": (i32, [vp, vp, pd, pd, pd, i32, i32, vp, i64, i64, vp, i64, i64, vp, vp, i64, i64, vp, vp, i64,
+                                    f64, f64, pd]),
     "gpfit_grad_pullback": (i32, [vp, vp, pd, i32, i32, vp, i64, i64, vp, i64, vp, pd]),
     "gpfit_nd_utility": (i32, [vp, vp, vp, i64, vp, i32, vp]),
     "gpfit_probe_mfma_f64": (i32, [vp, vp, i32, i32]),

@@ -785,6 +785,200 @@ static int fit_eval_projected_impl(gpfit_ctx* c, void* stream, const double* the
   return 0;
 }
 
+// Sparse M-step closure (n_tilde < n_t: K[n_t][n_tilde] != K~, a = K_b K~_b^-1 with non-zero da_p;
+// utils.py:2030-2099, 1114-1120), fused like the truncated-rank one above.  Two kernel objects (the
+// square K~ on the inducing stimuli and the rectangular K between training and inducing stimuli), the
+// same n x n algebra with a = K_b K~_b^-1 in place of B, and two adjoints to pull back:
+//   W~  = sym(B G_K~b B^T)   against dK~_p   (square pull-back on the inducing stimuli)
+//   W_K = G_Kb B^T           against dK_p    (rectangular pull-back, with the dKvec term riding on it)
+// (algebra of utils._closure_sparse).  The two d x d matrices are added before the one contraction
+// with dC_p, which is linear in them.
+static int fit_eval_sparse_impl(gpfit_ctx* c, void* stream, const double* theta, const double* lower,
+                                const double* upper, int n_rows, int n_cols, const double* X, int64_t ldx, int64_t N,
+                                const double* Xtilde, int64_t ldxt, int64_t Ntilde, const double* r, const double* B,
+                                int64_t ldb, int64_t n_kept, const double* m_b, const double* V_b, int64_t ldvb,
+                                double logA, double lambda0, double* out_host) {
+  using R = double;
+  if (!c || !theta || !X || !Xtilde || !r || !B || !m_b || !V_b || !out_host || N <= 0 || Ntilde <= 0 || n_kept <= 0 ||
+      n_kept > Ntilde) {
+    set_error("gpfit_fit_eval_sparse: bad argument");
+    return -3;
+  }
+  GP_CTX_ENTER(c, "gpfit_fit_eval_sparse");
+  const double inf = std::numeric_limits<double>::infinity();
+  if (lower && upper && check_limits(theta, lower, upper) != 0) {
+    out_host[0] = inf;
+    out_host[1] = out_host[2] = std::numeric_limits<double>::quiet_NaN();
+    for (int i = 0; i < 6; ++i) out_host[3 + i] = inf;
+    return -2;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  const int n1 = (int)N, n2 = (int)Ntilde, nk = (int)n_kept;
+  const int np1 = (int)round_up(N, TILE), np2 = (int)round_up(Ntilde, TILE), nb = (int)round_up(n_kept, TILE);
+  const int dfull = n_rows * n_cols;
+  if (np1 > c->np_cap || np2 > c->np_cap || dfull > c->dfull_cap) {
+    set_error("gpfit_fit_eval_sparse: problem larger than the context capacity");
+    return -3;
+  }
+  const int d = compute_mask(theta, n_rows, n_cols, nullptr, c->pix_host);
+  const int dp = (int)round_up(d, 32);
+  if (d <= 0 || dp > c->dp_cap) {
+    set_error("gpfit_fit_eval_sparse: masked pixel count is zero or exceeds the context capacity");
+    return -3;
+  }
+  const Theta th = make_theta(theta);
+  const double s0sq = th.sigma0 * th.sigma0, A = std::exp(logA);
+  const int64_t l2 = np2, lb = nb;
+  c->lv_valid = false; c->lv32_valid = false;
+  c->side_ev_next[0] = c->side_ev_next[1] = 0;
+  g_main_sk_ws = c->sk_ws[0];
+  double *X1m = c->Xm, *X2m = c->XDt, *Zm = c->XDt2;
+  double *Kt = c->Kbuf, *CosT = c->Cos, *Kr = c->Lbuf, *CosR = c->Libuf, *Bp = c->Tbuf, *Kb = c->Zbuf, *am = c->Tmp,
+         *aV = c->Abuf;
+  double *S1 = c->Vbuf, *S2 = c->LVbuf, *S3 = c->LiVbuf, *S4 = c->TmpV;
+  double *mbp = c->mpad, *bvec = c->yv, *gm = c->dq1, *gv = c->dq2, *gvec = c->hvec;
+  GP_HIP(hipMemsetAsync(c->info, 0, 4 * sizeof(int), s));
+  GP_HIP(hipMemcpyAsync(c->pix, c->pix_host, (size_t)d * sizeof(int), hipMemcpyHostToDevice, s));
+  // ---- kernel objects: C; training side (x: Xt, XCt, q, Kvec), inducing side (xtilde: Xt2, XCt2, q2)
+  GP_TRY(launch_localker<R>(th, c->pix, d, dp, n_rows, n_cols, c->Cmat, dp, nullptr, s));
+  GP_TRY(launch_gather(X, ldx, n1, c->pix, d, dp, np1, c->Xt, (int64_t)np1, X1m, dp, s));
+  GP_TRY(gemm<R>(s, 1, 1, dp, np1, dp, 1.0, c->Cmat, dp, c->Xt, np1, 0.0, c->XCt, np1, 0, 0, 0));
+  GP_TRY(launch_qvec(c->Xt, c->XCt, np1, dp, n1, np1, s0sq, c->Kvec, c->q, s));
+  GP_TRY(launch_gather(Xtilde, ldxt, n2, c->pix, d, dp, np2, c->Xt2, l2, X2m, dp, s));
+  GP_TRY(gemm<R>(s, 1, 1, dp, np2, dp, 1.0, c->Cmat, dp, c->Xt2, l2, 0.0, c->XCt2, l2, 0, 0, 0));
+  GP_TRY(launch_qvec(c->Xt2, c->XCt2, l2, dp, n2, np2, s0sq, c->hvec, c->q2, s));
+  {
+    GramArgsT<R> g{};  // K~ = acosker(xtilde, xtilde): lower tiles, mirrored below
+    g.XCt = c->XCt2; g.Xt = c->Xt2; g.q1 = c->q2; g.q2 = c->q2; g.Kout = Kt; g.Cos = CosT;
+    g.ld1 = l2; g.ld2 = l2; g.ldk = l2; g.np1 = np2; g.np2 = np2; g.nv1 = n2; g.nv2 = n2; g.Kd = dp;
+    g.s0sq = s0sq; g.lower = 1; g.pad_identity = 1;
+    GP_TRY(launch_gram(g, s));
+  }
+  GP_TRY(launch_symmetrize(Kt, l2, np2, s));
+  {
+    GramArgsT<R> g{};  // K = acosker(x, xtilde): rectangular, with its cosine matrix
+    g.XCt = c->XCt; g.Xt = c->Xt2; g.q1 = c->q; g.q2 = c->q2; g.Kout = Kr; g.Cos = CosR;
+    g.ld1 = np1; g.ld2 = l2; g.ldk = l2; g.np1 = np1; g.np2 = np2; g.nv1 = n1; g.nv2 = n2; g.Kd = dp;
+    g.s0sq = s0sq; g.lower = 0; g.pad_identity = 0;
+    g.ldcos = l2;
+    GP_TRY(launch_gram(g, s));
+  }
+  // ---- projection (:2047-2049, 2067-2068): K_b = K B, K~_b = sym(B^T K~ B), a = K_b K~_b^-1
+  GP_TRY(launch_pad_copy(B, ldb, n2, nk, Bp, lb, np2, nb, s));
+  GP_HIP(hipMemsetAsync(mbp, 0, (size_t)c->np_cap * sizeof(double), s));
+  GP_HIP(hipMemcpyAsync(mbp, m_b, (size_t)nk * sizeof(double), hipMemcpyDeviceToDevice, s));
+  GP_TRY(gemm<R>(s, 0, 1, np1, nb, np2, 1.0, Kr, l2, Bp, lb, 0.0, Kb, lb, 0, 0, 0));
+  GP_TRY(gemm<R>(s, 0, 1, np2, nb, np2, 1.0, Kt, l2, Bp, lb, 0.0, am, lb, 0, 0, 0));          // K~ B (temporary)
+  GP_TRY(gemm<R>(s, 1, 1, nb, nb, np2, 1.0, Bp, lb, am, lb, 0.0, S4, lb, 0, 0, 0));
+  GP_TRY(launch_symmetrize_avg(S4, lb, nk, s));
+  GP_TRY(launch_pack_lower(S4, lb, nk, S1, lb, nb, s));
+  {
+    CholBufsT<R> bk{S1, S2, S3, S4, lb, c->info + 0, 0, c->sk_ws[0]};
+    GP_TRY(potrf_rec<R>(bk, 0, nb, 1, s));
+  }
+  GP_TRY(launch_logdet(S2, lb, nk, c->scal + 3, s));
+  GP_TRY(gemm<R>(s, 1, 1, nb, nb, nb, 1.0, S3, lb, S3, lb, 0.0, S1, lb, 1, 2, 1));
+  GP_TRY(launch_symmetrize(S1, lb, nb, s));
+  double* Ki = S1;
+  GP_TRY(launch_pack_lower(V_b, ldvb, nk, S2, lb, nb, s));
+  GP_TRY(launch_symmetrize(S2, lb, nb, s));
+  GP_TRY(gemm<R>(s, 0, 1, nb, nb, nb, 1.0, Ki, lb, S2, lb, 0.0, S3, lb, 0, 0, 0));            // K~_b^-1 V_b
+  GP_TRY(launch_proj_trace(S3, lb, nk, c->scal + 5, s));
+  GP_TRY(gemm<R>(s, 0, 1, nb, nb, nb, 1.0, S3, lb, Ki, lb, 0.0, S4, lb, 0, 0, 0));            // P1
+  GP_TRY(gemm<R>(s, 0, 1, np1, nb, nb, 1.0, Kb, lb, Ki, lb, 0.0, am, lb, 0, 0, 0));           // a
+  GP_TRY(gemm<R>(s, 0, 1, np1, nb, nb, 1.0, am, lb, S2, lb, 0.0, aV, lb, 0, 0, 0));           // a V_b
+  {
+    CholBufsT<R> bv{S2, Kt, Kr, c->Wbuf, lb, c->info + 1, 0, c->sk_ws[0]};                    // K~ and K are dead
+    GP_TRY(potrf_rec<R>(bv, 0, nb, 0, s));
+  }
+  GP_TRY(launch_logdet(Kt, lb, nk, c->scal + 40, s));
+  GP_TRY(launch_symv_lower(Ki, lb, nb, mbp, bvec, s));
+  GP_TRY(launch_dot(mbp, bvec, nb, c->scal + 6, s));
+  // ---- moments / likelihood pieces with a = K_b K~_b^-1, per-point adjoints
+  GP_TRY(launch_proj_moments(am, Kb, aV, lb, nb, mbp, c->Kvec, r, n1, A, lambda0, c->lam_m, c->lam_var, c->fvec, gm, gv,
+                             c->upart, c->scal + 0, s));
+  double* Ga = Kt;       // [np1][nb]
+  double* GaKi = Kr;     // [np1][nb]
+  GP_TRY(launch_proj_ga(Kb, aV, lb, nb, n1, np1, gm, gv, mbp, Ga, s));
+  GP_TRY(gemm<R>(s, 0, 1, np1, nb, nb, 1.0, Ga, lb, Ki, lb, 0.0, GaKi, lb, 0, 0, 0));
+  GP_TRY(gemm<R>(s, 1, 1, nb, nb, np1, 1.0, am, lb, GaKi, lb, 0.0, c->Wbuf, lb, 0, 0, 0));    // P2 = a^T G_a K~_b^-1
+  GP_TRY(launch_proj_gktb(Ki, S4, c->Wbuf, lb, nb, bvec, S3, s));                            // G_K~b
+  GP_TRY(launch_proj_gkb(am, lb, nb, n1, np1, gv, GaKi, s));                                 // G_Kb (in place)
+  // ---- the two adjoints:  W~ = sym(B G_K~b B^T) [np2 x np2],  W_K = G_Kb B^T [np1 x np2]
+  GP_TRY(gemm<R>(s, 0, 1, np2, nb, nb, 1.0, Bp, lb, S3, lb, 0.0, Kt, lb, 0, 0, 0));           // B G_K~b  (G_a is dead)
+  GP_TRY(gemm<R>(s, 0, 0, np2, np2, nb, 1.0, Kt, lb, Bp, lb, 0.0, c->Wbuf, l2, 0, 0, 0));
+  GP_TRY(launch_symmetrize_avg(c->Wbuf, l2, np2, s));
+  GP_TRY(gemm<R>(s, 0, 0, np1, np2, nb, 1.0, GaKi, lb, Bp, lb, 0.0, aV, l2, 0, 0, 0));        // W_K  (a V_b is dead)
+  double* WK = aV;
+  // ---- square pull-back on the inducing stimuli (no b b^T term, no dKvec term)
+  GP_HIP(hipMemsetAsync(c->bv, 0, (size_t)c->np_cap * sizeof(R), s));
+  GP_HIP(hipMemsetAsync(c->wl, 0, (size_t)c->np_cap * sizeof(R), s));
+  GP_TRY(launch_adjoint(c->Wbuf, CosT, l2, c->bv, c->q2, n2, np2, Kb, c->upart, c->vpart, c->sumA_part, s));  // K_b is dead
+  const int t64 = np2 / 64;
+  GP_TRY(launch_adjoint_reduce(c->upart, c->vpart, c->sumA_part, t64, t64 * (t64 + 1) / 2, c->q2, c->wl, n2, np2, c->tvec,
+                               c->rpad, c->scal + 7, s));
+  GP_TRY(gemm<R>(s, 1, 1, np2, dp, np2, 1.0, Kb, l2, X2m, dp, 0.0, c->Ybuf, dp, 0, 0, 0));
+  GP_TRY(launch_rowscale_add(c->Ybuf, dp, X2m, dp, c->tvec, np2, dp, s));
+  auto xty = [&](const double* Xa, const double* Yb, int np, double* out) -> int {
+    GemmArgsT<R> g{};
+    g.A = Xa; g.B = Yb; g.C = c->Mpart; g.lda = dp; g.ldb = dp; g.ldc = dp;
+    g.M = dp; g.N = dp; g.K = np; g.alpha = 1.0; g.beta = 0.0; g.a_kmajor = 1; g.b_kmajor = 1;
+    g.batch = 1; g.split_k = c->split_k_M; g.sC = (int64_t)dp * dp;
+    GP_TRY(launch_gemm(g, s));
+    return launch_reduce_slices(c->Mpart, (int64_t)dp * dp, c->split_k_M, out, (int64_t)dp * dp, s);
+  };
+  GP_TRY(xty(X2m, c->Ybuf, np2, c->Mmat));
+  // ---- rectangular pull-back (x, xtilde) with gvec = -g_v on the training side (dKvec term)
+  GP_TRY(launch_scale_copy<R>(gvec, gv, n1, -1.0, s));
+  double* t1 = c->tvec;
+  double* t2 = c->tvec + c->np_cap;
+  GP_TRY(launch_adjoint_rect(WK, l2, CosR, l2, c->q, c->q2, n1, n2, np1, np2, Kt, l2, c->upart, c->vpart, c->rect_part,
+                             gvec, t1, t2, c->rpad, c->mpad, c->scal + 20, s));
+  GP_TRY(gemm<R>(s, 0, 1, np1, dp, np2, 1.0, Kt, l2, X2m, dp, 0.0, c->Ybuf, dp, 0, 0, 0));
+  GP_TRY(launch_rowscale_add(c->Ybuf, dp, X1m, dp, t1, np1, dp, s));
+  GP_HIP(hipMemsetAsync(Zm, 0, (size_t)np2 * dp * sizeof(double), s));
+  GP_TRY(launch_rowscale_add(Zm, dp, X2m, dp, t2, np2, dp, s));
+  GP_TRY(xty(X1m, c->Ybuf, np1, c->dCpad));
+  GP_TRY(launch_axpby_block<double>(c->Mmat, dp, c->dCpad, dp, dp, dp, 1.0, 1.0, s));
+  GP_TRY(xty(X2m, Zm, np2, c->dCpad));
+  GP_TRY(launch_axpby_block<double>(c->Mmat, dp, c->dCpad, dp, dp, dp, 1.0, 1.0, s));
+  GP_TRY(launch_symmetrize_avg(c->Mmat, dp, dp, s));
+  GP_TRY(launch_metric_contract(th, c->pix, d, n_rows, n_cols, c->Cmat, dp, c->Mmat, dp, c->scal + 10, s));
+  GP_HIP(hipMemcpyAsync(c->scal_host, c->scal, 64 * sizeof(double), hipMemcpyDeviceToHost, s));
+  GP_HIP(hipMemcpyAsync(c->info_host, c->info, 4 * sizeof(int), hipMemcpyDeviceToHost, s));
+  GP_HIP(hipStreamSynchronize(s));
+  const double* sc = c->scal_host;
+  const double loglik = A * sc[0] + lambda0 * sc[1] - sc[2];
+  const double KL = -0.5 * sc[40] + 0.5 * sc[3] + 0.5 * sc[6] + 0.5 * sc[5];
+  const double sum_gvec = 0.5 * A * A * sc[2];                                               // -sum g_v
+  out_host[0] = -(loglik - KL);
+  out_host[1] = loglik;
+  out_host[2] = KL;
+  out_host[3] = th.sigma0 * (2.0 * sc[9] + 2.0 * sc[7]) + th.sigma0 * (2.0 * sc[20] + sc[21] + sc[22]) +
+                2.0 * th.sigma0 * sum_gvec;
+  out_host[4] = sc[13];
+  out_host[5] = sc[14];
+  out_host[6] = sc[11];
+  out_host[7] = sc[12];
+  out_host[8] = sc[10];
+  out_host[9] = sc[3];
+  out_host[10] = sc[40];
+  out_host[11] = sc[5];
+  out_host[12] = sc[6];
+  out_host[13] = (double)d;
+  out_host[14] = (double)c->info_host[0];
+  out_host[15] = (double)c->info_host[1];
+  if (c->info_host[0] != 0) {
+    set_error("gpfit_fit_eval_sparse: Cholesky of the projected K_tilde failed (non-positive pivot)");
+    return c->info_host[0];
+  }
+  if (c->info_host[1] != 0) {
+    set_error("gpfit_fit_eval_sparse: Cholesky of V_b failed (non-positive pivot)");
+    return c->info_host[1];
+  }
+  return 0;
+}
+
 // Wait for the evaluation enqueued on this context and assemble its 16 host scalars.
 int fit_eval_finish(gpfit_ctx* c, double* out_host) {
   if (!c || !out_host || !c->pend.active) {
@@ -869,6 +1063,15 @@ int gpfit_fit_eval_projected(gpfit_ctx* c, void* stream, const double* theta, co
                              int64_t ldvb, double logA, double lambda0, double* out_host) {
   return fit_eval_projected_impl(c, stream, theta, lower, upper, n_rows, n_cols, X, ldx, N, r, B, ldb, n_kept, m_b, V_b,
                                  ldvb, logA, lambda0, out_host);
+}
+
+int gpfit_fit_eval_sparse(gpfit_ctx* c, void* stream, const double* theta, const double* lower, const double* upper,
+                          int n_rows, int n_cols, const double* X, int64_t ldx, int64_t N, const double* Xtilde,
+                          int64_t ldxt, int64_t Ntilde, const double* r, const double* B, int64_t ldb, int64_t n_kept,
+                          const double* m_b, const double* V_b, int64_t ldvb, double logA, double lambda0,
+                          double* out_host) {
+  return fit_eval_sparse_impl(c, stream, theta, lower, upper, n_rows, n_cols, X, ldx, N, Xtilde, ldxt, Ntilde, r, B, ldb,
+                              n_kept, m_b, V_b, ldvb, logA, lambda0, out_host);
 }
 
 int gpfit_grad_pullback(gpfit_ctx* c, void* stream, const double* theta, int n_rows, int n_cols, const double* X,

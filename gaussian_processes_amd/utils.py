@@ -854,6 +854,32 @@ def _closure_projected_steps(theta, lims, n_px_side, x, r, B, m_b, V_b, f_params
 
 
 def _closure_sparse(theta, lims, n_px_side, x, xtilde, r, B, m_b, V_b, f_params):
+    """Sparse M-step closure (n_tilde < n_t; utils.py:2030-2099, 1114-1120): ONE call of the fused entry
+    point ``gpfit_fit_eval_sparse``; the step-by-step formulation below (``_closure_sparse_steps``) is
+    the path taken when a factorisation meets a non-positive pivot (reference's eigen-fallback of
+    ``log_det``, utils.py:1279-1304)."""
+    lib = _lib.load()
+    lower, upper = lims
+    xc, xtc, rc, Bc, mc, Vc = _cu(x), _cu(xtilde), _cu(r), _cu(B), _cu(m_b), _cu(V_b)
+    rows, cols = _grid(n_px_side)
+    eng = get_engine(max(xc.shape[0], xtc.shape[0]), xc.shape[1], rows * cols)
+    out = (ctypes.c_double * 16)()
+    rc_ = lib.gpfit_fit_eval_sparse(eng._ctx, _stream(), _lib.darr(theta_vec(theta)),
+                                    _lib.darr([_scalar(lower[k]) for k in THETA_KEYS]),
+                                    _lib.darr([_scalar(upper[k]) for k in THETA_KEYS]), rows, cols,
+                                    xc.data_ptr(), xc.stride(0), xc.shape[0], xtc.data_ptr(), xtc.stride(0), xtc.shape[0],
+                                    rc.data_ptr(), Bc.data_ptr(), Bc.stride(0), Bc.shape[1], mc.data_ptr(), Vc.data_ptr(),
+                                    Vc.stride(0), _scalar(f_params['logA']), _scalar(_lambda0_of(f_params)), out)
+    if rc_ == -2:
+        raise ValueError(_lib.last_error())
+    if rc_ < 0:
+        _lib.check(rc_, "gpfit_fit_eval_sparse")
+    if rc_ == 0:
+        return out[0], {k: out[3 + i] for i, k in enumerate(THETA_KEYS)}
+    return _closure_sparse_steps(theta, lims, n_px_side, x, xtilde, r, B, m_b, V_b, f_params)
+
+
+def _closure_sparse_steps(theta, lims, n_px_side, x, xtilde, r, B, m_b, V_b, f_params):
     """Sparse M-step closure (n_tilde < n_t: K[n_t, n_tilde] != K~, a = K_b K~_b^-1 with non-zero
     da_p; utils.py:2030-2099, 1114-1120) in adjoint form.  Two adjoint matrices come out of the
     same algebra as in ``_closure_projected`` (with a = K_b K~_b^-1 this time):

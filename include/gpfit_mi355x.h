@@ -171,6 +171,20 @@ int gpfit_fit_eval_projected(gpfit_ctx* ctx, void* stream, const double* theta, 
                              const double* r, const double* B, int64_t ldb, int64_t n_kept, const double* m_b,
                              const double* V_b, int64_t ldvb, double logA, double lambda0, double* out_host);
 
+/* Sparse M-step closure, fused: n_tilde < n_t inducing stimuli (the regime of the lab's own fits,
+ * one_cell_fit.ipynb:89: n_t ~ 3160, n_tilde up to 2100): K[n_t][n_tilde] = acosker(x, xtilde) differs from
+ * K~ = acosker(xtilde, xtilde), a = K_b K~_b^-1 (utils.py:1693, 2068) and da_p is non-zero (:1114).
+ * X[N][ldx] training stimuli, Xtilde[Ntilde][ldxt] inducing stimuli (both un-masked), B[Ntilde][ldb] the
+ * kept eigenvectors of K~, m_b[n_kept], V_b[n_kept][ldvb].  As gpfit_fit_eval_projected, with two
+ * adjoints pulled back to the metric: B G_K~b B^T against dK~_p on the inducing stimuli and G_Kb B^T
+ * against dK_p on (x, xtilde), the dKvec term riding on the latter.  Same out_host and return
+ * conventions.  Synchronises. */
+int gpfit_fit_eval_sparse(gpfit_ctx* ctx, void* stream, const double* theta, const double* lower, const double* upper,
+                          int n_rows, int n_cols, const double* X, int64_t ldx, int64_t N, const double* Xtilde,
+                          int64_t ldxt, int64_t Ntilde, const double* r, const double* B, int64_t ldb, int64_t n_kept,
+                          const double* m_b, const double* V_b, int64_t ldvb, double logA, double lambda0,
+                          double* out_host);
+
 /* Cholesky factorisation A = L L^T of a symmetric positive definite n x n matrix (lower
  * triangle read) by the recursive MFMA algorithm; replaces torch.linalg.cholesky in log_det
  * (utils.py:1275) and, through L^-1, the LU torch.linalg.solve(., I) of the closure

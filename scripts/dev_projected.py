@@ -24,3 +24,19 @@ for name, fn in (("fused", gp._closure_projected), ("steps", gp._closure_project
         for _ in range(10): out = fn(th, (LOWER, UPPER), 16, X, r, B, m_b, V_b, fp)
         torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 10
     print(f"{name}: {dt*1e3:.2f} ms per closure, loss {out[0]:.9f} grad {[round(out[1][k], 6) for k in KEYS]}")
+# sparse closure: n_t = N, n_tilde = N/2
+nt_ = N // 2
+xt = X[:nt_].contiguous()
+Kt = gp.acosker(th, xt, xt, C=C)
+ev, evec = torch.linalg.eigh(Kt); keep = ev > max(float(ev.max()) * 1e-4, 1e-4)
+B = evec[:, keep].contiguous(); print("sparse: n_t", N, "n_tilde", nt_, "kept", B.shape[1])
+m_b = gp.matmul(B, m[:nt_].contiguous(), transA=True); V_b = torch.diag(ev[keep]) * 0.5
+del Kt, evec
+for name, fn in (("fused", gp._closure_sparse), ("steps", gp._closure_sparse_steps)):
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for _ in range(3): out = fn(th, (LOWER, UPPER), 16, X, xt, r, B, m_b, V_b, fp)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(10): out = fn(th, (LOWER, UPPER), 16, X, xt, r, B, m_b, V_b, fp)
+        torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 10
+    print(f"sparse {name}: {dt*1e3:.2f} ms per closure, loss {out[0]:.9f} grad {[round(out[1][k], 6) for k in KEYS]}")

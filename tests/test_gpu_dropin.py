@@ -146,10 +146,12 @@ def test_sparse_adjoint_closure(gp):
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         l1, g1 = gp._closure_general(th2, (LOWER, UPPER), 16, X, xt, r, B, m_b, V_b, fp, nt_, N)
-        l2, g2 = gp._closure_sparse(th2, (LOWER, UPPER), 16, X, xt, r, B, m_b, V_b, fp)
-    assert abs(l1 - l2) <= 1e-10 * abs(l1)
-    a1, a2 = np.array([g1[k] for k in KEYS]), np.array([g2[k] for k in KEYS])
+        l2, g2 = gp._closure_sparse(th2, (LOWER, UPPER), 16, X, xt, r, B, m_b, V_b, fp)           # fused entry point
+        l3, g3 = gp._closure_sparse_steps(th2, (LOWER, UPPER), 16, X, xt, r, B, m_b, V_b, fp)     # what it fuses
+    assert abs(l1 - l2) <= 1e-10 * abs(l1) and abs(l3 - l2) <= 1e-11 * abs(l3)
+    a1, a2, a3 = (np.array([g[k] for k in KEYS]) for g in (g1, g2, g3))
     assert np.abs(a1 - a2).max() <= 1e-7 * np.abs(a1).max()
+    assert np.abs(a3 - a2).max() <= 1e-9 * np.abs(a3).max()
 
 
 def test_fused_projected_closure_equals_step_by_step(gp):
