@@ -195,12 +195,8 @@ __global__ __launch_bounds__(RL_THREADS, 2) void chol_leaf_reg_kernel(const R* _
   using Acc = typename Real<R>::acc_t;
   using V = typename Real<R>::vec_t;
   constexpr int EPC = Real<R>::EPC;
-  // one LDS array: rows 0..127 the current panel P (raw S[., kb], then L[., kb]), rows 128..143 the
-  // inverse Dv of the 16 x 16 diagonal factor -- so that an operand fragment is "row block ia of LB"
-  // whatever it is (ia = 8 addresses Dv)
-  __shared__ __attribute__((aligned(16))) R LB[(RL + 16) * RPS];
-  R* const P = LB;
-  R* const Dv = LB + RL * RPS;
+  __shared__ __attribute__((aligned(16))) R P[RL * RPS];   // the current panel: raw S[., kb], then L[., kb]
+  __shared__ __attribute__((aligned(16))) R Dv[16 * RPS];  // inverse of the 16 x 16 diagonal factor
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int fr = lane & 15;
@@ -328,67 +324,34 @@ __global__ __launch_bounds__(RL_THREADS, 2) void chol_leaf_reg_kernel(const R* _
     }
     lds_barrier();
     if (wave == owner) LEAF_STAMP(kb, 5);
-    // ---- (3) every wave updates its own tiles from the panel.  The operand fragments of a slot are
-    //      read from LDS unconditionally, at addresses chosen by the slot's role, one slot ahead of
-    //      the MFMAs that use them (the roles differ per wave and panel, so they are run-time
-    //      branches around the MFMA groups; loads inside those branches would leave every slot's LDS
-    //      latency exposed between two dependent MFMA groups: 4.9 k instead of 2.6 k cycles here)
-    {
-      int offA[4], offC[4];
+    // ---- (3) every wave updates its own tiles from the panel
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        offA[r] = fr * RPS + kr[r];           // A/B fragment of a 16-row block: row fr, column k_r
-        offC[r] = (RL + kr[r]) * RPS + fr;    // C/D-layout image of Dv
-      }
-      auto load_ops = [&](int t, R (&a)[4], R (&b)[4]) {
-        const int i = slot_i(t), j = slot_j(t);
-        const bool xrow = (i == kb) && (j <= kb);
-        const bool xdiag = xrow && (j == kb);
-        const int ia = xrow ? 8 : i;          // X row: the fragment comes from Dv
+    for (int t = 0; t < 9; ++t) {
+      const int i = slot_i(t), j = slot_j(t);
+      if (j > kb) {
+        // Schur complement  S[i, j] -= L[i, kb] L[j, kb]^T
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          a[r] = LB[xdiag ? offC[r] : 16 * ia * RPS + offA[r]];
-          b[r] = LB[16 * j * RPS + offA[r]];
+        for (int r = 0; r < 4; ++r)
+          acc[t] = Real<R>::mfma(-P[(16 * i + fr) * RPS + kr[r]], P[(16 * j + fr) * RPS + kr[r]], acc[t]);
+      } else if (i == kb) {
+        // row kb of the inverse:  X[kb, kb] = Dinv,  X[kb, j] = -Dinv Y[kb, j]
+        Acc nx;
+        if (j == kb) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) nx[r] = Dv[kr[r] * RPS + fr];
+        } else {
+          nx = acc_zero<R>();
+#pragma unroll
+          for (int r = 0; r < 4; ++r) nx = Real<R>::mfma(-Dv[fr * RPS + kr[r]], acc[t][r], nx);
         }
-      };
-      R a0[4], b0[4];
-      load_ops(0, a0, b0);
+        acc[t] = nx;
+        xrow = nx;
+      } else if (i > kb) {
+        // running sums of the rows still to come:  Y[i, j] += L[i, kb] X[kb, j]
+        Acc y = (j == kb) ? acc_zero<R>() : acc[t];  // column kb held the raw panel until now
 #pragma unroll
-      for (int t = 0; t < 9; ++t) {
-        R a1[4], b1[4];
-        if (t + 1 < 9) load_ops(t + 1, a1, b1);
-        __builtin_amdgcn_sched_barrier(0);
-        const int i = slot_i(t), j = slot_j(t);
-        if (j > kb) {
-          // Schur complement  S[i, j] -= L[i, kb] L[j, kb]^T
-#pragma unroll
-          for (int r = 0; r < 4; ++r) acc[t] = Real<R>::mfma(-a0[r], b0[r], acc[t]);
-        } else if (i == kb) {
-          // row kb of the inverse:  X[kb, kb] = Dinv,  X[kb, j] = -Dinv Y[kb, j]
-          Acc nx;
-          if (j == kb) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) nx[r] = a0[r];
-          } else {
-            nx = acc_zero<R>();
-#pragma unroll
-            for (int r = 0; r < 4; ++r) nx = Real<R>::mfma(-a0[r], acc[t][r], nx);
-          }
-          acc[t] = nx;
-          xrow = nx;
-        } else if (i > kb) {
-          // running sums of the rows still to come:  Y[i, j] += L[i, kb] X[kb, j]
-          Acc y = (j == kb) ? acc_zero<R>() : acc[t];  // column kb held the raw panel until now
-#pragma unroll
-          for (int r = 0; r < 4; ++r) y = Real<R>::mfma(a0[r], xrow[r], y);
-          acc[t] = y;
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          a0[r] = a1[r];
-          b0[r] = b1[r];
-        }
+        for (int r = 0; r < 4; ++r) y = Real<R>::mfma(P[(16 * i + fr) * RPS + kr[r]], xrow[r], y);
+        acc[t] = y;
       }
     }
     lds_barrier();
