@@ -39,6 +39,7 @@ from gaussian_processes_amd import multi, synthetic as syn  # noqa: E402
 from gaussian_processes_amd.engine import GPFitEngine, fits_flops  # noqa: E402
 
 FP64_MFMA_PEAK_TFLOPS = 78.6  # MI355X dense fp64 matrix peak (AMD datasheet; rocBLAS dgemm reaches 76.7 on-box)
+NOMINAL_GHZ = 2.4                 # MI355X_MICROARCH.md: the clock the peak figures are quoted at
 FP32_MFMA_PEAK_TFLOPS = 157.3  # f32-input MFMA peak (MI355X_MICROARCH.md, chip-level parameters)
 
 
@@ -98,7 +99,10 @@ def profiled_mfma_util(kernel_name):
     try:
         for r in csv.reader(open(f)):
             if r and kernel_name in r[0]:
-                return {"mfma_pipe_utilisation": float(r[5]), "dispatches": int(r[1]), "source": os.path.basename(f)}
+                out = {"mfma_pipe_utilisation": float(r[5]), "dispatches": int(r[1]), "source": os.path.basename(f)}
+                if len(r) > 6:      # GRBM_GUI_ACTIVE / 8 XCDs / duration: the shader clock the launch really ran at
+                    out["shader_clock_ghz"] = float(r[6])
+                return out
     except Exception:
         pass
     return None
@@ -342,6 +346,7 @@ def main():
         dom_name = f"gemm_xcd_kernel<{rname}, false, true>"
         executed = prof["gemm_flops"] + prof["small_gemm_flops"] + prof["gram_flops"]
         nt = npad // 128
+        util = profiled_mfma_util(dom_name) if dtype_name == "f64" else None
         roofline = {
             "bound": "mfma",
             "kernel": dom_name + " (T = L^-1 L_V, N^3/3 flops, 1 launch/fit, XCD-aware macro-tile schedule; %s)"
@@ -352,9 +357,17 @@ def main():
             "achieved": round(dom_tflops, 2), "peak": peak, "unit": "TFLOP/s",
             "frac": round(dom_tflops / peak, 4),
             "traffic": profiled_traffic(dom_name, blocks=None) if dtype_name == "f64" else None,
-            "mfma_util": profiled_mfma_util(dom_name) if dtype_name == "f64" else None,
+            "mfma_util": util,
             "launches_per_fit": 1, "avg_launch_ms": round(prof["largest_gemm_ms"], 4),
             "algorithmic_flops_per_launch": dom_flops,
+            # `peak` is the nominal-clock figure (2.4 GHz).  The PMC pass shows the shader clock this launch
+            # really ran at (the fp64 GEMMs sit near 2.07 GHz in steady state, profiles/r02_clock_probe.txt);
+            # frac_at_measured_clock prices the same launch against the matrix peak at that clock.
+            "clock": None if not (util and util.get("shader_clock_ghz")) else {
+                "shader_clock_ghz": util["shader_clock_ghz"], "nominal_ghz": NOMINAL_GHZ,
+                "peak_at_measured_clock": round(peak * util["shader_clock_ghz"] / NOMINAL_GHZ, 2),
+                "frac_at_measured_clock": round(dom_tflops / (peak * util["shader_clock_ghz"] / NOMINAL_GHZ), 4),
+                "source": util["source"]},
             "gemm_family": {"what": "all 128-tile GEMM/SYRK/TRSM/TRTRI launches (gemm_mfma_kernel<..,128> + gemm_streamk_kernel), executed flops",
                             "launches_per_fit": prof["gemm_launches"], "tflops": round(gemm_tflops, 2),
                             "frac": round(gemm_tflops / peak, 4),

@@ -110,6 +110,11 @@ struct CholBufsT {
   int chain = 0;           // index into ctx->side / side_ev
   int side_min = 0;        // blocks of at least this size put their merge product on the side stream
   int half_occ = 0;        // bit 0: this chain's own 128-tile launches run one workgroup per CU; bit 1: its side-stream products do
+  // optional: record mark_ev on the chain's stream once the leading mark_n x mark_n block is factored
+  // (the other chain can be started there, so that its latency-bound leaf stretches meet this chain's
+  // large products instead of this chain's leaf stretches)
+  hipEvent_t mark_ev = nullptr;
+  int mark_n = 0;
 };
 using CholBufs = CholBufsT<double>;
 // Recursive blocked Cholesky of the n x n diagonal block at offset r0 (n a multiple of 128),

@@ -149,6 +149,7 @@ int potrf_rec(const CholBufsT<R>& B, int r0, int n, int need_inv, hipStream_t s)
   const int n1 = ((k + 1) / 2) * TILE, n2 = n - n1;
   const int r1 = r0 + n1;
   GP_TRY(potrf_rec<R>(B, r0, n1, 1, s));
+  if (B.mark_ev && r0 == 0 && n1 == B.mark_n) GP_HIP(hipEventRecord(B.mark_ev, s));
   // L21 = A21 * L11^-T       (trsm as a GEMM against the explicit inverse; op(B) = Li11^T is upper)
   GP_TRY(gemm<R>(s, 0, 0, n2, n1, n1, 1.0, at(B.A, r1, r0), ld, at(B.Li, r0, r0), ld, 0.0, at(B.L, r1, r0), ld, 0, 0, 2, walks()[0], B.ws, B.sk_ws, false, B.half_occ & 1));
   // Look-ahead: tmp = L21 * Li11, the first product of the inverse merge, needs nothing from the second
@@ -480,14 +481,22 @@ static int fit_eval_impl(gpfit_ctx* c, void* stream, const double* theta, const 
   GP_TRY(launch_moments(RP(c->Kvec), RP(c->q), RP(c->Cos), ld, V, ldv, m, r, n, A, lambda0, RP(c->lam_m), RP(c->lam_var), RP(c->fvec),
                         RP(c->wl), c->scal, s));
   phase(1, s);
-  if (fork_late) {
+  // tuning knob: start the V chain only when the K~ chain has factored its leading block of this size
+  static const int v_after = getenv("GPFIT_V_AFTER") ? atoi(getenv("GPFIT_V_AFTER")) : 0;
+  const bool v_marked = fork_late && !async_call && v_after >= TILE && v_after < np;
+  if (fork_late && !v_marked) {
     GP_HIP(hipEventRecord(c->ev_fork, s));
     GP_HIP(hipStreamWaitEvent(sa, c->ev_fork, 0));
     GP_TRY(enqueue_v_chain());
   }
   {
     CholBufsT<R> bk{RP(c->Kbuf), RP(c->Lbuf), RP(c->Libuf), RP(c->Tmp), ld, c->info + 0, 0, c->sk_ws[0], c, 0, side_min, half_occ & 2};
+    if (v_marked) { bk.mark_ev = c->ev_fork; bk.mark_n = v_after; }
     GP_TRY(potrf_rec<R>(bk, 0, np, true, s));
+    if (v_marked) {
+      GP_HIP(hipStreamWaitEvent(sa, c->ev_fork, 0));
+      GP_TRY(enqueue_v_chain());
+    }
   }
   GP_TRY(launch_logdet(RP(c->Lbuf), ld, n, c->scal + 3, s));
   GP_TRY(launch_trmv_lower(RP(c->Libuf), ld, np, RP(c->mpad), RP(c->yv), s));       // y = L^-1 m

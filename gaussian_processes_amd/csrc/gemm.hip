@@ -107,10 +107,26 @@ __global__ __launch_bounds__(GEMM_THREADS, (T == 128 || NS > 2 ? 2 : 4)) void ge
 // (gemm_sched.hip): in the fit these are exactly T = L^-1 L_V (<R, false, true>) and Q = I - T T^T
 // (<R, false, false>), one launch each per evaluation, so a profiler's per-kernel row for this name
 // IS that launch.
+#ifdef GPFIT_CLOCK_STAMPS
+// Diagnostic build only (scripts/dev_gemm_clock.sh): shader cycles (s_memtime) and 100 MHz ticks
+// (s_memrealtime) each workgroup of the last scheduled launch spent, [B_KMAJOR][block][2]; read back with
+// hipMemcpyFromSymbol by gpfit_dev_gemm_clock.  No output value depends on them.
+__device__ long long g_gemm_clock[2][4096][2];
+#endif
+
 template <typename R, bool A_KMAJOR, bool B_KMAJOR>
 __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_xcd_kernel(GemmArgsT<R> p, int tiles_n, int ntiles) {
   __shared__ __attribute__((aligned(16))) R smem[4 * Real<R>::KT * TILE];
+#ifdef GPFIT_CLOCK_STAMPS
+  const long long t0 = __builtin_amdgcn_s_memtime(), w0 = __builtin_amdgcn_s_memrealtime();
+#endif
   gemm_tile_body<R, A_KMAJOR, B_KMAJOR, false, TILE, 2>(p, tiles_n, ntiles, smem);
+#ifdef GPFIT_CLOCK_STAMPS
+  if (threadIdx.x == 0 && blockIdx.x < 4096) {
+    g_gemm_clock[B_KMAJOR ? 1 : 0][blockIdx.x][0] = (long long)__builtin_amdgcn_s_memtime() - t0;
+    g_gemm_clock[B_KMAJOR ? 1 : 0][blockIdx.x][1] = (long long)__builtin_amdgcn_s_memrealtime() - w0;
+  }
+#endif
 }
 
 // Tile size: 128 when that already gives the chip >= 1.5 waves of blocks, otherwise 64 / 32 so
@@ -236,3 +252,9 @@ template int gemm_pick_tile<double>(const GemmArgsT<double>&);
 template int gemm_pick_tile<float>(const GemmArgsT<float>&);
 
 }  // namespace gpfit
+
+#ifdef GPFIT_CLOCK_STAMPS
+extern "C" int gpfit_dev_gemm_clock(long long* host_out /* [2][4096][2] */) {
+  return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(gpfit::g_gemm_clock), sizeof(long long) * 2 * 4096 * 2) == hipSuccess ? 0 : -1;
+}
+#endif

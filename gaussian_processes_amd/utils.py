@@ -7,8 +7,10 @@ hand-written HIP library ``libgpfit_mi355x.so`` through ctypes.  torch supplies 
 memory, streams and (for the rank decision only) ``torch.linalg.eigh``.
 
 There is no CPU fallback: without a GPU or without the built library every entry point raises.
-Out of scope (SURVEY.md section 2 rows 10-14,16-19): plotting, pickling helpers, the dataset
-container, the active-learning utility.
+``save_model`` / ``load_model`` keep the reference's on-disk layout (model_io.py).
+Out of scope (SURVEY.md section 2 rows 10-14,16-19): plotting, the dataset container, and the
+reference's dead code (``utility`` / ``get_utility`` scalar variants, ``block_matrix_inverse``, ``updateA``,
+``linker``: no caller in the reference's own files).
 """
 from __future__ import annotations
 
@@ -22,6 +24,7 @@ import torch
 
 from . import _lib
 from .engine import GPFitEngine, _grid, theta_vec
+from .model_io import load_model, save_model  # noqa: F401  (utils.py:46, 312)
 from .synthetic import THETA_KEYS
 
 torch.set_grad_enabled(False)  # reference utils.py:2 (analytic gradients only)

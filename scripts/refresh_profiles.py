@@ -14,19 +14,22 @@ with open(os.path.join(P, f"{tag}_configs.jsonl"), "w") as o:
     o.writelines(l for l in open(os.path.join(G, f"{tag}_configs.jsonl")) if l.startswith("{"))
 f = max(glob.glob(os.path.join(G, f"{tag}_pmcm", "*", "*_counter_collection.csv")), key=os.path.getmtime)
 agg = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = collections.Counter()
+dur = collections.Counter()
 for r in csv.DictReader(open(f)):
     k = r["Kernel_Name"].split("(")[0]
     agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
     if r["Counter_Name"] == "GRBM_GUI_ACTIVE":
         cnt[k] += 1
+        dur[k] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
 with open(os.path.join(P, f"{tag}_mfma_busy.csv"), "w") as o:
     w = csv.writer(o)
     w.writerow(["kernel", "dispatches", "SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE", "busy_per_active",
-                "mfma_pipe_utilisation = busy_per_active / 128 (1024 SIMDs / 8 XCD counters)"])
+                "mfma_pipe_utilisation = busy_per_active / 128 (1024 SIMDs / 8 XCD counters)",
+                "shader_clock_ghz = GRBM_GUI_ACTIVE / 8 XCDs / kernel duration in ns"])
     for k, v in sorted(agg.items(), key=lambda kv: -kv[1].get("GRBM_GUI_ACTIVE", 0)):
         mf, ga = v.get("SQ_VALU_MFMA_BUSY_CYCLES", 0), v.get("GRBM_GUI_ACTIVE", 1)
         if mf > 0:
-            w.writerow([k, cnt[k], f"{mf:.4e}", f"{ga:.4e}", f"{mf/ga:.2f}", f"{mf/ga/128:.3f}"])
+            w.writerow([k, cnt[k], f"{mf:.4e}", f"{ga:.4e}", f"{mf/ga:.2f}", f"{mf/ga/128:.3f}", f"{ga/8/max(dur[k], 1):.3f}"])
 for name in (f"{tag}_bench.json", f"{tag}_bench_f32.json"):
     j = json.load(open(os.path.join(P, name))); r = j["roofline"]
     print(name, j["value"], j["unit"], j["ms_per_step"], "ms; roofline", r["achieved"], r["frac"], r["avg_launch_ms"], "family", r["gemm_family"]["tflops"],

@@ -396,6 +396,29 @@ def test_predict_at_iteration_matches_reference(gp, name):
     assert relerr(R_pred.cpu().numpy(), g["R_pred"]) > 1e-3      # it really is a different state
 
 
+def test_saved_model_predicts_like_the_live_one(gp, tmp_path):
+    """save_model -> load_model(map_location=cuda) -> test(**model) (the notebooks' sequence,
+    one_cell_fit.ipynb) reproduces the live fit's prediction bit for bit; the description carries the
+    tracked start -> end values."""
+    import os
+    g = load_golden("g6_vargp_trunc_N128.npz")
+    fit, err, R_pred = _run_vargp(gp, g)
+    target = os.path.join(tmp_path, "saved_fit")
+    gp.save_model(fit, target, additional_description="g6 trunc")
+    back = gp.load_model(target, map_location="cuda:0")
+    assert "Model Description" in back["description"] and "g6 trunc" in back["description"]
+    old = gp.EIGVAL_TOL
+    gp.EIGVAL_TOL = float(g["tol"])
+    try:
+        with contextlib.redirect_stdout(io.StringIO()), warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            Rt = T(np.random.default_rng(5).poisson(0.7, (4, 6, 1)).astype(np.float64))
+            _, R_again, _, _ = gp.test(T(g["Xstar"]), Rt, X_train=T(g["X"]), at_iteration=None, **back)
+    finally:
+        gp.EIGVAL_TOL = old
+    assert torch.equal(R_again, R_pred)
+
+
 def test_vargp_error_rollback_matches_reference(gp):
     """varGP's error branch (utils.py:2127-2231): a fault injected into the kernel rebuild of EM
     iteration 3 (the third grad=False call of the module-level ``localker``, the same injection
