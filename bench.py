@@ -335,7 +335,9 @@ def main():
         gemm_tflops = prof["gemm_flops"] / (prof["gemm_ms"] * 1e-3) / 1e12 if prof["gemm_ms"] > 0 else 0.0
         # dominant kernel = the single largest launch: T = L^-1 L_V (both operands lower triangular, lower
         # output; algorithmic flops N^3/3): one launch per fit of
-        # gemm_xcd_kernel<R, false, true> (the 128-tile body on the XCD-aware schedule, gemm_sched.hip), so its
+        # gemm_epi_kernel<R, false, true, 2> (the 128-tile body on the XCD-aware schedule, gemm_sched.hip, with the
+        # tile-norm epilogue that leaves ||T||_F^2 behind; gemm_xcd_kernel<R, false, true> when GPFIT_FUSED_EPI
+        # switches that epilogue off), so its
         # rocprofv3 kernel_stats row is this launch's average.
         npad = -(-N // 128) * 128
         dom_flops = float(npad) ** 3 / 3.0
@@ -343,7 +345,8 @@ def main():
         rname = "double" if dtype_name == "f64" else "float"   # the dominant launch (T) runs in fp32 in the mixed mode
         if dtype_name == "mixed":
             peak = FP32_MFMA_PEAK_TFLOPS
-        dom_name = f"gemm_xcd_kernel<{rname}, false, true>"
+        fused_norm = int(os.environ.get("GPFIT_FUSED_EPI", "7")) & 2
+        dom_name = f"gemm_epi_kernel<{rname}, false, true, 2>" if fused_norm else f"gemm_xcd_kernel<{rname}, false, true>"
         executed = prof["gemm_flops"] + prof["small_gemm_flops"] + prof["gram_flops"]
         nt = npad // 128
         util = profiled_mfma_util(dom_name) if dtype_name == "f64" else None

@@ -65,6 +65,17 @@ struct GemmArgsT {
                              // of holding every workgroup slot of the chip for its whole duration
   const int* sched;          // device tile table of an XCD-aware schedule (gemm_sched.hip), or nullptr
   int sched_blocks;          // its length = the grid size
+  // Fused epilogues of the data-parallel launches (gemm.hip; a launch that takes the stream-K schedule cannot
+  // honour them -- ask gemm_epilogue_ok() first).  Bit mask:
+  //   1  mirror: square lower output, every stored element below the diagonal is also stored transposed
+  //      (replaces a symmetrisation pass over the matrix)
+  //   2  tile norms: sumsq[ti (ti + 1) / 2 + tj] = sum of squares of the stored values of 128-tile (ti, tj)
+  //      (lower output, 128-tile launches only; replaces a pass over the matrix)
+  //   4  dual update: with D = aux (same leading dimension as C), C = alpha op(A) op(B) + D and then
+  //      aux = C + D (beta is ignored; replaces a copy and an axpby pass)
+  int epi;
+  R* aux;
+  double* sumsq;
 };
 using GemmArgs = GemmArgsT<double>;
 
@@ -80,6 +91,10 @@ template <typename R> int launch_gemm_streamk(const GemmArgsT<R>& a, hipStream_t
 template <typename R> int launch_gemm_plain(const GemmArgsT<R>& a, hipStream_t s);  // data-parallel launch, no stream-K
 // XCD-aware data-parallel schedule (gemm_sched.hip): 0 issued, 1 not applicable.  Walk bit 3 asks for it.
 template <typename R> int launch_gemm_xcd(const GemmArgsT<R>& a, hipStream_t s);
+// would launch_gemm run these arguments on a data-parallel schedule (plain or XCD-aware), i.e. honour a.epi?
+template <typename R> bool gemm_epilogue_ok(const GemmArgsT<R>& a);
+template <typename R> bool gemm_streamk_applies(const GemmArgsT<R>& a);   // gemm_streamk.hip
+template <typename R> bool gemm_xcd_applies(const GemmArgsT<R>& a);       // gemm_sched.hip
 
 // Arc-cosine Gram matrix from the k-major, zero-padded operands XCt[Kd][ld1], Xt[Kd][ld2]:
 //   G = XCt^T Xt + s0^2 ; c = clip(G/(q1 q2 + 1e-7)) ; K = q1 q2 J(c)

@@ -250,6 +250,13 @@ int launch_frob_lower(const R* T, int64_t ldt, int np, double* out, double* part
   return 0;
 }
 
+// out = sum of the nt per-tile sums of squares a GEMM with the tile-norm epilogue left in partial
+int launch_frob_finish(const double* partial, int nt, double* out, hipStream_t s) {
+  hipLaunchKernelGGL(sum_kernel<double>, dim3(1), dim3(1024), 0, s, partial, nt, 1.0, out);
+  GP_HIP(hipGetLastError());
+  return 0;
+}
+
 template <typename R>
 __global__ void trmv_lower_kernel(const R* __restrict__ L, int64_t ldl, int np, const R* __restrict__ x,
                                   R* __restrict__ y) {
@@ -571,43 +578,67 @@ int launch_rowscale_add(R* Y, int64_t ldy, const R* Xm, int64_t ldm, const R* t,
 // ------------------------------------------------------------------ metric contraction
 // grad5[p] = sum_kl dC_p[k][l] M[k][l], dC_p rebuilt from C and the pixel coordinates
 // (utils.py:902-909), order Amp, -2log2beta, -log2rho2, eps_0x, eps_0y.
+// METRIC_BLOCKS workgroups take the rows of the d x d matrices cyclically; each leaves its five partial
+// sums in part[block][5] and the last one to arrive (ticket counter, reset for the next call) adds the
+// partials in block order, so the result does not depend on the arrival order.  (The single-workgroup
+// version of round 1 took 105 us at d = 256, at the end of every evaluation's critical path.)
+constexpr int METRIC_BLOCKS = 32;
 template <typename R>
-__global__ void metric_contract_kernel(Theta th, const int* __restrict__ pix, int d, int n_rows, int n_cols,
-                                       const R* __restrict__ C, int64_t ldc, const R* __restrict__ M, int64_t ldm,
-                                       double* __restrict__ grad5) {
+__global__ __launch_bounds__(256) void metric_contract_kernel(Theta th, const int* __restrict__ pix, int d, int n_rows,
+                                                              int n_cols, const R* __restrict__ C, int64_t ldc,
+                                                              const R* __restrict__ M, int64_t ldm,
+                                                              double* __restrict__ grad5, double* __restrict__ part,
+                                                              int* __restrict__ ticket) {
   __shared__ double sh[17];
+  __shared__ int last;
   double g[5] = {0, 0, 0, 0, 0};
-  const int64_t total = (int64_t)d * d;
-  for (int64_t e = threadIdx.x; e < total; e += blockDim.x) {
-    const int i = (int)(e / d), j = (int)(e % d);
-    const int pi = pix[i], pj = pix[j];
+  for (int i = blockIdx.x; i < d; i += gridDim.x) {
+    const int pi = pix[i];
     const double xi = lin_pm1(pi % n_cols, n_cols), yi = lin_pm1(pi / n_cols, n_rows);
-    const double xj = lin_pm1(pj % n_cols, n_cols), yj = lin_pm1(pj / n_cols, n_rows);
-    const double dxi = xi - th.eps0x, dyi = yi - th.eps0y, dxj = xj - th.eps0x, dyj = yj - th.eps0y;
+    const double dxi = xi - th.eps0x, dyi = yi - th.eps0y;
     const double lai = -th.eb * (dxi * dxi + dyi * dyi);
-    const double laj = -th.eb * (dxj * dxj + dyj * dyj);
-    const double ex = xj - xi, ey = yj - yi;
-    const double ls = -th.er * (ex * ex + ey * ey);
-    const double c = (double)C[(int64_t)i * ldc + j];
-    const double mm = (double)M[(int64_t)i * ldm + j];
-    g[0] += (c / th.amp) * mm;
-    g[1] += (c * (lai + laj)) * mm;
-    g[2] += (c * ls) * mm;
-    g[3] += (2.0 * th.eb * c * (xi + xj - 2.0 * th.eps0x)) * mm;
-    g[4] += (2.0 * th.eb * c * (yi + yj - 2.0 * th.eps0y)) * mm;
+    for (int j = threadIdx.x; j < d; j += blockDim.x) {
+      const int pj = pix[j];
+      const double xj = lin_pm1(pj % n_cols, n_cols), yj = lin_pm1(pj / n_cols, n_rows);
+      const double dxj = xj - th.eps0x, dyj = yj - th.eps0y;
+      const double laj = -th.eb * (dxj * dxj + dyj * dyj);
+      const double ex = xj - xi, ey = yj - yi;
+      const double ls = -th.er * (ex * ex + ey * ey);
+      const double c = (double)C[(int64_t)i * ldc + j];
+      const double mm = (double)M[(int64_t)i * ldm + j];
+      g[0] += (c / th.amp) * mm;
+      g[1] += (c * (lai + laj)) * mm;
+      g[2] += (c * ls) * mm;
+      g[3] += (2.0 * th.eb * c * (xi + xj - 2.0 * th.eps0x)) * mm;
+      g[4] += (2.0 * th.eb * c * (yi + yj - 2.0 * th.eps0y)) * mm;
+    }
   }
 #pragma unroll
   for (int p = 0; p < 5; ++p) {
     const double v = block_sum(g[p], sh);
-    if (threadIdx.x == 0) grad5[p] = v;
+    if (threadIdx.x == 0) part[blockIdx.x * 5 + p] = v;
   }
+  if (threadIdx.x == 0) {
+    __threadfence();                                    // partials visible before the ticket
+    last = (atomicAdd(ticket, 1) == (int)gridDim.x - 1);
+  }
+  __syncthreads();
+  if (!last) return;
+  __threadfence();
+  if (threadIdx.x < 5) {
+    double v = 0.0;
+    for (int b = 0; b < (int)gridDim.x; ++b) v += __hip_atomic_load(&part[b * 5 + threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    grad5[threadIdx.x] = v;
+  }
+  if (threadIdx.x == 0) *ticket = 0;
 }
 
+// part: >= 5 * METRIC_BLOCKS doubles of scratch; ticket: a device int that is 0 between calls
 template <typename R>
 int launch_metric_contract(const Theta& th, const int* pix, int d, int n_rows, int n_cols, const R* C, int64_t ldc,
-                           const R* M, int64_t ldm, double* grad5, hipStream_t s) {
-  hipLaunchKernelGGL(metric_contract_kernel<R>, dim3(1), dim3(1024), 0, s, th, pix, d, n_rows, n_cols, C, ldc, M,
-                     ldm, grad5);
+                           const R* M, int64_t ldm, double* grad5, double* part, int* ticket, hipStream_t s) {
+  hipLaunchKernelGGL(metric_contract_kernel<R>, dim3(METRIC_BLOCKS), dim3(256), 0, s, th, pix, d, n_rows, n_cols, C,
+                     ldc, M, ldm, grad5, part, ticket);
   GP_HIP(hipGetLastError());
   return 0;
 }
@@ -941,7 +972,7 @@ int launch_fparam(const double* lam_m, const double* lam_var, const double* r, i
   template int launch_rowscale_add<R>(R*, int64_t, const R*, int64_t, const R*, int, int, hipStream_t);             \
   template int launch_reduce_slices<R, R>(const R*, int64_t, int, R*, int64_t, hipStream_t);                        \
   template int launch_metric_contract<R>(const Theta&, const int*, int, int, int, const R*, int64_t, const R*,      \
-                                         int64_t, double*, hipStream_t);                                            \
+                                         int64_t, double*, double*, int*, hipStream_t);                             \
   template int launch_add_diag<R>(R*, int64_t, int, double, hipStream_t);                                           \
   template int launch_axpby_block<R>(R*, int64_t, const R*, int64_t, int, int, double, double, hipStream_t);          \
   template int launch_scale_copy<R>(R*, const R*, int, double, hipStream_t);

@@ -111,9 +111,9 @@ double gemm_flops(const GemmArgsT<R>& g) {
 
 // ------------------------------------------------------------------ GEMM convenience
 template <typename R>
-static int gemm(hipStream_t s, int a_kmajor, int b_kmajor, int M, int N, int K, double alpha, const R* A,
-                int64_t lda, const R* B, int64_t ldb, double beta, R* C, int64_t ldc, int out_lower, int a_tri,
-                int b_tri, int reverse = 0, int ws = 0, void* sk_ws = nullptr, bool plain = false, int half_occ = 0) {
+static GemmArgsT<R> gemm_args(int a_kmajor, int b_kmajor, int M, int N, int K, double alpha, const R* A, int64_t lda,
+                              const R* B, int64_t ldb, double beta, R* C, int64_t ldc, int out_lower, int a_tri,
+                              int b_tri, int reverse = 0, int ws = 0, void* sk_ws = nullptr, int half_occ = 0) {
   GemmArgsT<R> g{};
   g.A = A; g.B = B; g.C = C;
   g.lda = lda; g.ldb = ldb; g.ldc = ldc;
@@ -123,9 +123,29 @@ static int gemm(hipStream_t s, int a_kmajor, int b_kmajor, int M, int N, int K, 
   g.out_lower = out_lower; g.a_tri = a_tri; g.b_tri = b_tri;
   g.batch = 1; g.split_k = 1; g.reverse = reverse; g.workspace = ws; g.sk_ws = sk_ws ? sk_ws : g_main_sk_ws;
   g.half_occ = half_occ;
+  return g;
+}
+
+template <typename R>
+static int run_gemm(hipStream_t s, const GemmArgsT<R>& g, bool plain = false) {
   // profile kind 0: the 128-tile kernel family (the dominant kernel), 3: the small-tile instances
   ProfScope ps(s, g_prof ? gemm_flops(g) : 0.0, (g_prof && gemm_pick_tile(g) != TILE) ? 3 : 0);
-  return (plain || half_occ) ? launch_gemm_plain(g, s) : launch_gemm(g, s);  // plain: data-parallel, never stream-K
+  return (plain || g.half_occ) ? launch_gemm_plain(g, s) : launch_gemm(g, s);  // plain: data-parallel, never stream-K
+}
+
+template <typename R>
+static int gemm(hipStream_t s, int a_kmajor, int b_kmajor, int M, int N, int K, double alpha, const R* A,
+                int64_t lda, const R* B, int64_t ldb, double beta, R* C, int64_t ldc, int out_lower, int a_tri,
+                int b_tri, int reverse = 0, int ws = 0, void* sk_ws = nullptr, bool plain = false, int half_occ = 0) {
+  return run_gemm(s, gemm_args<R>(a_kmajor, b_kmajor, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, out_lower, a_tri, b_tri,
+                                  reverse, ws, sk_ws, half_occ), plain);
+}
+
+// tuning knob (bit mask, default all): fused GEMM epilogues -- 1 Q's symmetrisation, 2 T's norm, 4 the H / Z21 update
+// of the two-sided product
+static int fused_epilogues() {
+  static const int v = getenv("GPFIT_FUSED_EPI") ? atoi(getenv("GPFIT_FUSED_EPI")) : 7;
+  return v;
 }
 
 #define GP_TRY(expr)            \
@@ -218,12 +238,22 @@ static int two_sided(const TwoSidedBufs<R>& b, int r0, int n, hipStream_t s) {
   R* H21 = at(b.H, r1, r0);
   // Z21 = 1/2 Q22 B
   GP_TRY(gemm<R>(s, 1, 1, n2, n1, n2, 0.5, at(b.Q, r1, r1), ld, at(b.Li, r1, r0), ld, 0.0, Z21, ld, 0, 0, 0));
-  // H = Q21 A + Z21
-  GP_HIP(hipMemcpy2DAsync(H21, (size_t)ld * sizeof(R), Z21, (size_t)ld * sizeof(R), (size_t)n1 * sizeof(R), (size_t)n2,
-                          hipMemcpyDeviceToDevice, s));
-  GP_TRY(gemm<R>(s, 0, 1, n2, n1, n1, 1.0, at(b.Q, r1, r0), ld, at(b.Li, r0, r0), ld, 1.0, H21, ld, 0, 0, 1, walks()[6]));
-  // Z21 = H + 1/2 Q22 B ;  W21 = 1/2 C^T Z21
-  GP_TRY(launch_axpby_block<R>(Z21, ld, H21, ld, n2, n1, 1.0, 1.0, s));
+  // H = Q21 A + Z21 ;  Z21 = H + 1/2 Q22 B  (one launch with the dual-update epilogue: H = acc + Z21, Z21 += H;
+  // otherwise a copy, the product with beta = 1 and an axpby pass -- the same arithmetic)
+  {
+    GemmArgsT<R> g = gemm_args<R>(0, 1, n2, n1, n1, 1.0, at(b.Q, r1, r0), ld, at(b.Li, r0, r0), ld, 0.0, H21, ld, 0, 0, 1, walks()[6]);
+    g.epi = 4; g.aux = Z21;
+    if ((fused_epilogues() & 4) && gemm_epilogue_ok(g)) {
+      GP_TRY(run_gemm(s, g));
+    } else {
+      GP_HIP(hipMemcpy2DAsync(H21, (size_t)ld * sizeof(R), Z21, (size_t)ld * sizeof(R), (size_t)n1 * sizeof(R), (size_t)n2,
+                              hipMemcpyDeviceToDevice, s));
+      g.epi = 0; g.aux = nullptr; g.beta = 1.0;
+      GP_TRY(run_gemm(s, g));
+      GP_TRY(launch_axpby_block<R>(Z21, ld, H21, ld, n2, n1, 1.0, 1.0, s));
+    }
+  }
+  // W21 = 1/2 C^T Z21
   static const int w21_walk = getenv("GPFIT_W21_WALK") ? atoi(getenv("GPFIT_W21_WALK")) : 0;
   GP_TRY(gemm<R>(s, 1, 1, n2, n1, n2, 0.5, at(b.Li, r1, r1), ld, Z21, ld, 0.0, at(b.W, r1, r0), ld, 0, 2, 0, w21_walk));
   // W11 = 1/2 A^T Q11 A + 1/2 (B^T H + H^T B)   (lower tiles)
@@ -308,10 +338,18 @@ static int post_join(gpfit_ctx* c, const PostJoin<R>& a, const Theta& th, int n,
     static const int t_plain_min = getenv("GPFIT_T_PLAIN_MIN") ? atoi(getenv("GPFIT_T_PLAIN_MIN")) : (1 << 30);
     static const int t_plain_walk = getenv("GPFIT_T_PLAIN_WALK") ? atoi(getenv("GPFIT_T_PLAIN_WALK")) : 6;
     const bool dp = np >= t_plain_min;
-    GP_TRY(gemm<R>(s, 0, 1, np, np, np, 1.0, a.Li, ld, a.LV, ld, 0.0, a.T, ld, 1, 1, 1,
-                   dp ? t_plain_walk : walks()[3], 0, nullptr, dp));
+    GemmArgsT<R> g = gemm_args<R>(0, 1, np, np, np, 1.0, a.Li, ld, a.LV, ld, 0.0, a.T, ld, 1, 1, 1, dp ? t_plain_walk : walks()[3]);
+    g.epi = 2; g.sumsq = c->frob_part;
+    if ((fused_epilogues() & 2) && !dp && gemm_epilogue_ok(g)) {
+      // the tiles leave their sums of squares behind: no separate pass over T
+      GP_TRY(run_gemm(s, g));
+      GP_TRY(launch_frob_finish(c->frob_part, (np / TILE) * (np / TILE + 1) / 2, c->scal + 5, s));
+    } else {
+      g.epi = 0; g.sumsq = nullptr;
+      GP_TRY(run_gemm(s, g, dp));
+      GP_TRY(launch_frob_lower(a.T, ld, np, c->scal + 5, c->frob_part, s));
+    }
   }
-  GP_TRY(launch_frob_lower(a.T, ld, np, c->scal + 5, c->frob_part, s));
   phase(4, s);
 
   if (want_grad) {
@@ -325,11 +363,14 @@ static int post_join(gpfit_ctx* c, const PostJoin<R>& a, const Theta& th, int n,
       // stream-K 3.2); GPFIT_Q_PLAIN_MIN restores the column-major walk above that size
       static const int q_plain_min = getenv("GPFIT_Q_PLAIN_MIN") ? atoi(getenv("GPFIT_Q_PLAIN_MIN")) : (1 << 30);
       const bool dp = np >= q_plain_min;
-      GP_TRY(gemm<R>(s, 0, 0, np, np, np, -1.0, a.T, ld, a.T, ld, 0.0, a.W, ld, 1, 1, 2,
-                     dp ? 3 : walks()[4], 0, nullptr, dp));
+      GemmArgsT<R> g = gemm_args<R>(0, 0, np, np, np, -1.0, a.T, ld, a.T, ld, 0.0, a.W, ld, 1, 1, 2, dp ? 3 : walks()[4]);
+      g.epi = 1;
+      const bool mirrored = (fused_epilogues() & 1) && !dp && gemm_epilogue_ok(g);
+      if (!mirrored) g.epi = 0;
+      GP_TRY(run_gemm(s, g, dp));
+      GP_TRY(launch_add_diag(a.W, ld, np, 1.0, s));
+      if (!mirrored) GP_TRY(launch_symmetrize(a.W, ld, np, s));   // otherwise the tiles stored their transposes
     }
-    GP_TRY(launch_add_diag(a.W, ld, np, 1.0, s));
-    GP_TRY(launch_symmetrize(a.W, ld, np, s));
     phase(5, s);
     {
       static const int ts_min = getenv("GPFIT_TS_MIN") ? atoi(getenv("GPFIT_TS_MIN")) : 4096;
@@ -357,7 +398,7 @@ static int post_join(gpfit_ctx* c, const PostJoin<R>& a, const Theta& th, int n,
       }
       GP_TRY(launch_reduce_slices(a.Mpart, (int64_t)dp * dp, c->split_k_M, a.Mmat, (int64_t)dp * dp, s));
     }
-    GP_TRY(launch_metric_contract(th, c->pix, d, n_rows, n_cols, a.Cmat, dp, a.Mmat, dp, c->scal + 10, s));
+    GP_TRY(launch_metric_contract(th, c->pix, d, n_rows, n_cols, a.Cmat, dp, a.Mmat, dp, c->scal + 10, c->upart, c->info + 3, s));
   }
 
   return 0;
@@ -615,7 +656,7 @@ static int grad_pullback_impl(gpfit_ctx* c, void* stream, const double* theta, i
     GP_TRY(launch_gemm(g, s));
     GP_TRY(launch_reduce_slices(RP(c->Mpart), (int64_t)dp * dp, c->split_k_M, RP(c->Mmat), (int64_t)dp * dp, s));
   }
-  GP_TRY(launch_metric_contract(th, c->pix, d, n_rows, n_cols, RP(c->Cmat), dp, RP(c->Mmat), dp, c->scal + 10, s));
+  GP_TRY(launch_metric_contract(th, c->pix, d, n_rows, n_cols, RP(c->Cmat), dp, RP(c->Mmat), dp, c->scal + 10, c->upart, c->info + 3, s));
   GP_HIP(hipMemcpyAsync(c->scal_host, c->scal, 64 * sizeof(double), hipMemcpyDeviceToHost, s));
   GP_HIP(hipStreamSynchronize(s));
   const double* sc = c->scal_host;
@@ -760,7 +801,7 @@ static int fit_eval_projected_impl(gpfit_ctx* c, void* stream, const double* the
     GP_TRY(launch_gemm(g, s));
     GP_TRY(launch_reduce_slices(c->Mpart, (int64_t)dp * dp, c->split_k_M, c->Mmat, (int64_t)dp * dp, s));
   }
-  GP_TRY(launch_metric_contract(th, c->pix, d, n_rows, n_cols, c->Cmat, dp, c->Mmat, dp, c->scal + 10, s));
+  GP_TRY(launch_metric_contract(th, c->pix, d, n_rows, n_cols, c->Cmat, dp, c->Mmat, dp, c->scal + 10, c->upart, c->info + 3, s));
   GP_HIP(hipMemcpyAsync(c->scal_host, c->scal, 64 * sizeof(double), hipMemcpyDeviceToHost, s));
   GP_HIP(hipMemcpyAsync(c->info_host, c->info, 4 * sizeof(int), hipMemcpyDeviceToHost, s));
   GP_HIP(hipStreamSynchronize(s));
@@ -952,7 +993,7 @@ static int fit_eval_sparse_impl(gpfit_ctx* c, void* stream, const double* theta,
   GP_TRY(xty(X2m, Zm, np2, c->dCpad));
   GP_TRY(launch_axpby_block<double>(c->Mmat, dp, c->dCpad, dp, dp, dp, 1.0, 1.0, s));
   GP_TRY(launch_symmetrize_avg(c->Mmat, dp, dp, s));
-  GP_TRY(launch_metric_contract(th, c->pix, d, n_rows, n_cols, c->Cmat, dp, c->Mmat, dp, c->scal + 10, s));
+  GP_TRY(launch_metric_contract(th, c->pix, d, n_rows, n_cols, c->Cmat, dp, c->Mmat, dp, c->scal + 10, c->upart, c->info + 3, s));
   GP_HIP(hipMemcpyAsync(c->scal_host, c->scal, 64 * sizeof(double), hipMemcpyDeviceToHost, s));
   GP_HIP(hipMemcpyAsync(c->info_host, c->info, 4 * sizeof(int), hipMemcpyDeviceToHost, s));
   GP_HIP(hipStreamSynchronize(s));

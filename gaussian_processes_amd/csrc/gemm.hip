@@ -13,19 +13,22 @@ namespace gpfit {
 // NS = LDS stages of the main loop (gemm_core.h): 2 everywhere except the "deep" small-tile
 // instances (4 at T = 64, 8 at T = 32) the launcher picks when a launch has at most two
 // workgroups per CU, i.e. when nothing else hides the load latency.
+// Tile selection, k range and main loop of one workgroup: on return acc holds op(A) op(B) of tile (ti, tj) at
+// (row0, col0) and C points at this batch / split's output; false when the block has no tile (schedule padding).
 template <typename R, bool A_KMAJOR, bool B_KMAJOR, bool EDGE, int T, int NS>
-__device__ __forceinline__ void gemm_tile_body(const GemmArgsT<R>& p, int tiles_n, int ntiles, R* smem) {
+__device__ __forceinline__ bool gemm_tile_compute(const GemmArgsT<R>& p, int tiles_n, int ntiles, R* smem,
+                                                  typename Real<R>::acc_t (&acc)[T / 32][T / 32], int& ti, int& tj,
+                                                  int& row0, int& col0, R*& C) {
   constexpr int KT = Real<R>::KT;
 
   // heaviest tiles first: with triangular operands the k range depends on the tile position,
   // so the launcher asks for the walk that starts with the long ones (shorter tail):
   // bit 0 = walk backwards, bit 1 = column-major (dense output only).
   const int bid = (p.reverse & 1) ? (ntiles - 1 - (int)blockIdx.x) : (int)blockIdx.x;
-  int ti, tj;
   if (p.sched != nullptr) {
     // XCD-aware schedule: the table says which tile this block id computes (-1: padding entry)
     const int e = p.sched[blockIdx.x];
-    if (e < 0) return;
+    if (e < 0) return false;
     ti = e >> 16;
     tj = e & 0xffff;
   } else if (p.out_lower && (p.reverse & 2) && T == TILE) {
@@ -47,11 +50,12 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgsT<R>& p, int tiles_
     ti = bid / tiles_n;
     tj = bid % tiles_n;
   }
-  const int row0 = ti * T, col0 = tj * T;
+  row0 = ti * T;
+  col0 = tj * T;
   const int b = blockIdx.y, z = blockIdx.z;
   const R* A = p.A + (int64_t)b * p.sA;
   const R* B = p.B + (int64_t)b * p.sB;
-  R* C = p.C + (int64_t)b * p.sC;
+  C = p.C + (int64_t)b * p.sC;
 
   int kbeg = 0, kend = p.K;
   if (p.a_tri == 1) kend = min(kend, row0 + T);
@@ -68,7 +72,6 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgsT<R>& p, int tiles_
     C += (int64_t)z * p.sC;
   }
 
-  typename Real<R>::acc_t acc[T / 32][T / 32];
 #pragma unroll
   for (int i = 0; i < T / 32; ++i)
 #pragma unroll
@@ -77,10 +80,58 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgsT<R>& p, int tiles_
   // walk bit 2: k downwards (EDGE instances ignore it)
   gemm_mainloop<R, A_KMAJOR, B_KMAJOR, EDGE, T, 0, NS>(A, p.lda, B, p.ldb, p.M, p.N, row0, col0, kbeg, kend, smem, acc,
                                                        (p.reverse & 4) != 0);
+  return true;
+}
+
+// EPI: fused epilogue compiled into this instance (common.h GemmArgsT::epi; 0 = the plain alpha / beta store).
+template <typename R, bool A_KMAJOR, bool B_KMAJOR, bool EDGE, int T, int NS, int EPI = 0>
+__device__ __forceinline__ void gemm_tile_body(const GemmArgsT<R>& p, int tiles_n, int ntiles, R* smem) {
+  typename Real<R>::acc_t acc[T / 32][T / 32];
+  int ti, tj, row0, col0;
+  R* C;
+  if (!gemm_tile_compute<R, A_KMAJOR, B_KMAJOR, EDGE, T, NS>(p, tiles_n, ntiles, smem, acc, ti, tj, row0, col0, C)) return;
 
   const R alpha = (R)p.alpha, beta = (p.split_k > 1) ? (R)0 : (R)p.beta;
   const int64_t ldc = p.ldc;
   const int M = p.M, N = p.N;
+  if constexpr (EPI != 0) {
+    // fused epilogues (common.h: 1 mirror, 2 tile norms, 4 dual update); the launcher has checked that the
+    // launch is data-parallel on full tiles
+    constexpr int epi = EPI;
+    R* __restrict__ D = p.aux;
+    double ss = 0.0;
+    for_each_acc<R, T>(acc, row0, col0, [&](int row, int col, R v) {
+      if (EDGE && !(row < M && col < N)) return;
+      R o = alpha * v;
+      R* c = C + (int64_t)row * ldc + col;
+      if (epi & 4) {
+        R* dd = D + (int64_t)row * ldc + col;
+        const R d0 = *dd;
+        o += d0;
+        *dd = o + d0;
+      } else if (beta != (R)0) {
+        o += beta * (*c);
+      }
+      if (epi & 1) {
+        // the diagonal tile's strict upper part comes from the transposed store of its lower part
+        if (row >= col) *c = o;
+        if (row > col) C[(int64_t)col * ldc + row] = o;
+      } else {
+        *c = o;
+      }
+      if (epi & 2) ss += (double)o * (double)o;
+    });
+    if (epi & 2) {
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) ss += __shfl_down(ss, o);
+      double* red = reinterpret_cast<double*>(smem);
+      __syncthreads();  // every wave is done with the operand stages
+      if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ss;
+      __syncthreads();
+      if (threadIdx.x == 0) p.sumsq[(int64_t)ti * (ti + 1) / 2 + tj] = (red[0] + red[1]) + (red[2] + red[3]);
+    }
+    return;
+  }
   if (beta == (R)0) {
     for_each_acc<R, T>(acc, row0, col0, [&](int row, int col, R v) {
       if (!EDGE || (row < M && col < N)) C[(int64_t)row * ldc + col] = alpha * v;
@@ -123,6 +174,22 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_xcd_kernel(GemmArgsT<R> 
   gemm_tile_body<R, A_KMAJOR, B_KMAJOR, false, TILE, 2>(p, tiles_n, ntiles, smem);
 #ifdef GPFIT_CLOCK_STAMPS
   if (threadIdx.x == 0 && blockIdx.x < 4096) {
+    g_gemm_clock[B_KMAJOR ? 1 : 0][blockIdx.x][0] = (long long)__builtin_amdgcn_s_memtime() - t0;
+    g_gemm_clock[B_KMAJOR ? 1 : 0][blockIdx.x][1] = (long long)__builtin_amdgcn_s_memrealtime() - w0;
+  }
+#endif
+}
+
+// The 128-tile body with a fused epilogue (common.h GemmArgsT::epi), with or without a schedule table.
+template <typename R, bool A_KMAJOR, bool B_KMAJOR, int EPI>
+__global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_epi_kernel(GemmArgsT<R> p, int tiles_n, int ntiles) {
+  __shared__ __attribute__((aligned(16))) R smem[4 * Real<R>::KT * TILE];
+#ifdef GPFIT_CLOCK_STAMPS
+  const long long t0 = __builtin_amdgcn_s_memtime(), w0 = __builtin_amdgcn_s_memrealtime();
+#endif
+  gemm_tile_body<R, A_KMAJOR, B_KMAJOR, false, TILE, 2, EPI>(p, tiles_n, ntiles, smem);
+#ifdef GPFIT_CLOCK_STAMPS
+  if (threadIdx.x == 0 && blockIdx.x < 4096 && EPI != 4) {
     g_gemm_clock[B_KMAJOR ? 1 : 0][blockIdx.x][0] = (long long)__builtin_amdgcn_s_memtime() - t0;
     g_gemm_clock[B_KMAJOR ? 1 : 0][blockIdx.x][1] = (long long)__builtin_amdgcn_s_memrealtime() - w0;
   }
@@ -181,6 +248,17 @@ static void launch_T(const GemmArgsT<R>& p, hipStream_t s) {
       hipLaunchKernelGGL((gemm_mfma_kernel<R, AK, BK, ED, T, 2>), grid, block, HALF_OCC_LDS, s, p, tn, tiles); \
     } else hipLaunchKernelGGL((gemm_mfma_kernel<R, AK, BK, ED, T, 2>), grid, block, 0, s, p, tn, tiles); \
   } while (0)
+  if (p.epi) {
+    // fused epilogues exist for the layouts the fit uses: T = L^-1 L_V with tile norms, Q = -T T^T mirrored,
+    // H = Q21 A + Z21 with the dual update (gemm_epilogue_ok has checked the combination)
+    if constexpr (T == TILE) {
+      const int key = p.epi * 4 + (p.a_kmajor ? 2 : 0) + (p.b_kmajor ? 1 : 0);
+      if (key == 2 * 4 + 1) hipLaunchKernelGGL((gemm_epi_kernel<R, false, true, 2>), grid, block, 0, s, p, tn, tiles);
+      else if (key == 1 * 4 + 0) hipLaunchKernelGGL((gemm_epi_kernel<R, false, false, 1>), grid, block, 0, s, p, tn, tiles);
+      else if (key == 4 * 4 + 1) hipLaunchKernelGGL((gemm_epi_kernel<R, false, true, 4>), grid, block, 0, s, p, tn, tiles);
+    }
+    return;
+  }
   if (p.sched && T == TILE && !edge) {
     switch ((p.a_kmajor ? 2 : 0) | (p.b_kmajor ? 1 : 0)) {
       case 0: hipLaunchKernelGGL((gemm_xcd_kernel<R, false, false>), grid, block, 0, s, p, tn, tiles); break;
@@ -205,8 +283,32 @@ static void launch_T(const GemmArgsT<R>& p, hipStream_t s) {
 }
 
 template <typename R>
+bool gemm_epilogue_ok(const GemmArgsT<R>& a) {
+  if (a.split_k > 1 || a.batch > 1 || a.M <= 0 || a.N <= 0) return false;
+  const int T = gemm_pick_tile(a);
+  if ((a.M % T) || (a.N % T)) return false;                                    // full tiles only
+  if ((a.epi & 1) && (!a.out_lower || a.M != a.N)) return false;
+  if ((a.epi & 2) && (T != TILE || !a.out_lower)) return false;
+  if ((a.epi & 4) && a.aux == nullptr) return false;
+  // instances that exist (launch_T): 128-tile, row-major A, and per mode the operand layout the fit uses
+  if (T != TILE || a.a_kmajor || a.half_occ) return false;
+  if (!((a.epi == 2 && a.b_kmajor) || (a.epi == 1 && !a.b_kmajor) || (a.epi == 4 && a.b_kmajor))) return false;
+  if (T == TILE && a.tile_limit == 0) {
+    if ((a.reverse & 8) && gemm_xcd_applies(a)) return true;
+    if (gemm_streamk_applies(a)) return false;
+  }
+  return true;
+}
+template bool gemm_epilogue_ok<double>(const GemmArgsT<double>&);
+template bool gemm_epilogue_ok<float>(const GemmArgsT<float>&);
+
+template <typename R>
 int launch_gemm(const GemmArgsT<R>& a, hipStream_t s) {
   if (a.M <= 0 || a.N <= 0) return 0;
+  if (a.epi && !gemm_epilogue_ok(a)) {
+    set_error("launch_gemm: this launch cannot carry a fused epilogue (ask gemm_epilogue_ok first)");
+    return -3;
+  }
   if (a.half_occ) return launch_gemm_plain(a, s);
   if (a.tile_limit == 0 && gemm_pick_tile(a) == TILE && a.batch <= 1) {
     if (a.reverse & 8) {

@@ -110,15 +110,22 @@ static int build(const GemmArgsT<R>& a, Plan& plan) {
 }
 
 template <typename R>
-int launch_gemm_xcd(const GemmArgsT<R>& a, hipStream_t s) {
-  if ((a.M % TILE) || (a.N % TILE) || a.split_k > 1 || a.batch > 1 || (a.tile && a.tile != TILE)) return 1;
-  if (a.out_lower && a.M != a.N) return 1;
+bool gemm_xcd_applies(const GemmArgsT<R>& a) {
+  if ((a.M % TILE) || (a.N % TILE) || a.split_k > 1 || a.batch > 1 || (a.tile && a.tile != TILE)) return false;
+  if (a.out_lower && a.M != a.N) return false;
   const long tm = a.M / TILE, tn = a.N / TILE;
-  if (tm >= 32768 || tn >= 32768) return 1;
+  if (tm >= 32768 || tn >= 32768) return false;
   // A data-parallel schedule needs several rounds of the 512 resident workgroups to balance; below
   // that the stream-K / heavy-first walks win (N = 4096: 528 tiles, 7.27 vs 7.5 ms per fit).
   static const long min_tiles = getenv("GPFIT_XCD_MIN_TILES") ? atol(getenv("GPFIT_XCD_MIN_TILES")) : 1536;
-  if ((a.out_lower ? tm * (tm + 1) / 2 : tm * tn) < min_tiles) return 1;
+  return (a.out_lower ? tm * (tm + 1) / 2 : tm * tn) >= min_tiles;
+}
+template bool gemm_xcd_applies<double>(const GemmArgsT<double>&);
+template bool gemm_xcd_applies<float>(const GemmArgsT<float>&);
+
+template <typename R>
+int launch_gemm_xcd(const GemmArgsT<R>& a, hipStream_t s) {
+  if (!gemm_xcd_applies(a)) return 1;
   int device = 0;
   GP_HIP(hipGetDevice(&device));
   Plan plan;

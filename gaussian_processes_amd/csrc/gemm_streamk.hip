@@ -211,16 +211,17 @@ static int build_plan(const GemmArgsT<R>& a, int first, SkPlan& plan) {
 //    rounds stay data-parallel -- workgroups that start together walk k in lock step and share
 //    operand panels in L2, which stream-K's staggered shares give up -- and only the tail tiles
 //    are cut along k over the whole chip.
+// first: number of leading tiles that stay data-parallel (tails of uniform launches); -1: not a stream-K launch
 template <typename R>
-int launch_gemm_streamk(const GemmArgsT<R>& a, hipStream_t s) {
+static int streamk_first_tile(const GemmArgsT<R>& a) {
   static const bool disabled = getenv("GPFIT_NO_STREAMK") != nullptr;
-  if (disabled) return 1;
-  if ((a.M % TILE) || (a.N % TILE) || a.split_k > 1 || a.batch > 1 || (a.tile && a.tile != TILE)) return 1;
+  if (disabled) return -1;
+  if ((a.M % TILE) || (a.N % TILE) || a.split_k > 1 || a.batch > 1 || (a.tile && a.tile != TILE)) return -1;
   const long tm = a.M / TILE, tn = a.N / TILE;
   const int ntiles = (int)(a.out_lower ? tm * (tm + 1) / 2 : tm * tn);
   static const int sk_min = getenv("GPFIT_SK_MIN_TILES") ? atoi(getenv("GPFIT_SK_MIN_TILES")) : 384;
   static const int sk_all = getenv("GPFIT_SK_ALL") ? 1 : 0;  // experiment: stream-K for every eligible launch
-  if (ntiles < sk_min || (long)a.K < 1024) return 1;  // small launches: latency-, not balance-bound
+  if (ntiles < sk_min || (long)a.K < 1024) return -1;  // small launches: latency-, not balance-bound
   int first = 0;
   // classes of launches that take the stream-K schedule (tuning knob, bit mask): 1 operands
   // triangular on both sides, 2 lower output with an upper-triangular op(A), 4 tails of uniform
@@ -228,15 +229,27 @@ int launch_gemm_streamk(const GemmArgsT<R>& a, hipStream_t s) {
   // (heavy rows first) is the faster one (2.86 vs 3.04 ms at N = 8192).
   static const int sk_classes = getenv("GPFIT_SK_CLASSES") ? atoi(getenv("GPFIT_SK_CLASSES")) : 5;
   const bool cls1 = (a.a_tri != 0 && a.b_tri != 0), cls2 = (a.out_lower && a.a_tri == 2 && a.b_tri == 0);
-  if ((cls1 && !(sk_classes & 1)) || (cls2 && !(sk_classes & 2))) return 1;
+  if ((cls1 && !(sk_classes & 1)) || (cls2 && !(sk_classes & 2))) return -1;
   const bool both_tri = cls1 || cls2;
-  if (!both_tri && !(sk_classes & 4)) return 1;
+  if (!both_tri && !(sk_classes & 4)) return -1;
   if (!both_tri && !(sk_all && ntiles < SK_SLOTS)) {
-    if (a.a_tri || a.b_tri) return 1;       // one-sided triangles: the heavy-first walk already balances
+    if (a.a_tri || a.b_tri) return -1;       // one-sided triangles: the heavy-first walk already balances
     const int tail = ntiles % SK_SLOTS;
-    if (tail == 0 || tail >= 384 || ntiles < SK_SLOTS) return 1;
+    if (tail == 0 || tail >= 384 || ntiles < SK_SLOTS) return -1;
     first = ntiles - tail;
   }
+  return first;
+}
+
+template <typename R>
+bool gemm_streamk_applies(const GemmArgsT<R>& a) { return streamk_first_tile(a) >= 0; }
+template bool gemm_streamk_applies<double>(const GemmArgsT<double>&);
+template bool gemm_streamk_applies<float>(const GemmArgsT<float>&);
+
+template <typename R>
+int launch_gemm_streamk(const GemmArgsT<R>& a, hipStream_t s) {
+  const int first = streamk_first_tile(a);
+  if (first < 0 || a.epi) return 1;   // fused epilogues live in the data-parallel kernels only
   int device = 0;
   GP_HIP(hipGetDevice(&device));
   SkPlan plan;

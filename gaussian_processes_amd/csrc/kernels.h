@@ -86,7 +86,9 @@ int launch_reduce_slices(const RI* src, int64_t slice_stride, int nslice, RO* ds
 // grad5[p] = sum_kl dC_p[k][l] * M[k][l] for the five metric hyperparameters, dC recomputed from C
 template <typename R>
 int launch_metric_contract(const Theta& th, const int* pix, int d, int n_rows, int n_cols, const R* C, int64_t ldc,
-                           const R* M, int64_t ldm, double* grad5, hipStream_t s);
+                           const R* M, int64_t ldm, double* grad5, double* part /* >= 160 doubles */,
+                           int* ticket /* device int, 0 between calls */, hipStream_t s);
+int launch_frob_finish(const double* partial, int nt, double* out, hipStream_t s);
 template <typename R> int launch_add_diag(R* A, int64_t lda, int n, double v, hipStream_t s);
 template <typename R> int launch_scale_copy(R* dst, const R* src, int n, double alpha, hipStream_t s);
 // dst = a * dst + b * src over a rows x cols block (cols even)

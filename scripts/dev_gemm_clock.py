@@ -34,7 +34,7 @@ lib.gpfit_dev_gemm_clock.restype = ctypes.c_int
 buf = (ctypes.c_longlong * (2 * 4096 * 2))()
 assert lib.gpfit_dev_gemm_clock(buf) == 0
 a = np.frombuffer(buf, dtype=np.int64).reshape(2, 4096, 2)
-for which, name in ((1, "T = L^-1 L_V   (gemm_xcd_kernel<double,false,true>)"), (0, "Q = I - T T^T   (gemm_xcd_kernel<double,false,false>)")):
+for which, name in ((1, "T = L^-1 L_V   (gemm_epi_kernel<double,false,true,2>)"), (0, "Q = I - T T^T   (gemm_epi_kernel<double,false,false,1>)")):
     st = a[which]; ok = st[:, 1] > 0
     ghz = st[ok, 0] / (st[ok, 1] * 10.0)
     print(f"{name}: {ok.sum()} workgroups, in-kernel clock median {np.median(ghz):.3f} GHz (p10 {np.percentile(ghz,10):.3f}, p90 {np.percentile(ghz,90):.3f}); "
