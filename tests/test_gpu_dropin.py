@@ -676,6 +676,72 @@ def test_rank_decision_without_eigh(gp):
     assert relerr(fit_a["V_b"].cpu().numpy(), gp.matmul(Bb, gp.matmul(fit_b["V_b"], Bb, transB=True)).cpu().numpy()) < 1e-6
 
 
+def _bench_kernel_matrix(gp, N, d=256):
+    dev = torch.device("cuda:0")
+    X = T(syn.stimuli(N, d)).to(dev)
+    th0 = {k: torch.tensor(v, dtype=torch.float64) for k, v in syn.theta0().items()}
+    C, mask = gp.localker(th0, UPPER, LOWER, syn.grid_for(d))
+    return X, gp.acosker(th0, X, X, C=C)
+
+
+def test_truncated_basis_without_full_eigh(gp):
+    """Truncated regime at N = 4096 (the reference's default EIGVAL_TOL keeps ~515 of 4096 directions,
+    utils.py:1683): the block-subspace solver (eigtop.py) returns the same count, the same eigenvalues
+    (1e-12) and the same invariant subspace (1e-10) as torch.linalg.eigh, twice the same bits, and
+    _stabilised_basis takes that route."""
+    from gaussian_processes_amd import eigtop
+    X, K = _bench_kernel_matrix(gp, 4096)
+    w, U = torch.linalg.eigh(K, UPLO='L')
+    keep = w > max(float(w[-1]) * gp.EIGVAL_TOL, gp.EIGVAL_TOL)
+    out = eigtop.top_eigenpairs(K, gp.EIGVAL_TOL, gp.matmul, gp.cholesky)
+    assert out is not None
+    vals, vecs, info = out
+    assert 0 < int(keep.sum()) < 4096 // 4 and vals.shape[0] == int(keep.sum())
+    assert float(((vals - w[keep]).abs() / w[keep]).max()) < 1e-12
+    P = U[:, keep].T @ vecs
+    eye = torch.eye(P.shape[0], dtype=torch.float64, device=P.device)
+    assert float((P.T @ P - eye).abs().max()) < 1e-10              # same subspace
+    assert float((vecs.T @ vecs - eye).abs().max()) < 1e-12        # orthonormal
+    assert bool((vecs.abs().max(0).values == vecs.max(0).values).all())   # sign convention
+    again = eigtop.top_eigenpairs(K, gp.EIGVAL_TOL, gp.matmul, gp.cholesky)
+    assert torch.equal(again[0], vals) and torch.equal(again[1], vecs)
+    eigvecs, B, Kb, Kib = gp._stabilised_basis(K)
+    assert torch.equal(B, vecs) and torch.equal(torch.diagonal(Kb), vals)
+    # a rule that keeps more than a third of the spectrum is not a truncation problem: the solver declines
+    assert eigtop.top_eigenpairs(K, 1e-6, gp.matmul, gp.cholesky, max_sweeps=16) is None
+
+
+def test_closure_in_the_subspace_basis_equals_the_eigh_basis(gp):
+    """The M-step closure (fused projected entry point) evaluated in the basis from the subspace solver and in
+    the basis from torch.linalg.eigh, same (m, V) expressed in each: loss 1e-10, gradients 1e-8."""
+    N, d = 4096, 256
+    X, K = _bench_kernel_matrix(gp, N, d)
+    r_np, m_np = syn.cell_inputs(N)
+    r, m = T(r_np).cuda(), T(m_np).cuda()
+    V = 0.5 * K
+    old = gp._FORCE_EIGH
+    res = []
+    for force in (False, True):
+        gp._FORCE_EIGH = force
+        try:
+            _, B, Kb, Kib = gp._stabilised_basis(K)
+        finally:
+            gp._FORCE_EIGH = old
+        m_b = gp.matmul(B, m, transA=True)
+        V_b = gp.matmul(gp.matmul(B, V, transA=True), B)
+        V_b = (V_b + V_b.T) * 0.5
+        th = tth([syn.theta_eval()[k] for k in KEYS])
+        f_params = {"logA": torch.tensor(syn.F_PARAMS["logA"], dtype=torch.float64),
+                    "lambda0": torch.tensor(syn.F_PARAMS["lambda0"], dtype=torch.float64)}
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            loss, grad = gp._closure_projected(th, (LOWER, UPPER), 16, X, r, B, m_b, V_b, f_params)
+        res.append((float(loss), np.array([grad[k] for k in KEYS]), B.shape[1]))
+    (l0, g0, n0), (l1, g1, n1) = res
+    assert n0 == n1 and abs(l0 - l1) <= 1e-10 * abs(l1), (l0, l1)
+    assert np.abs(g0 - g1).max() <= 1e-8 * np.abs(g1).max(), (g0, g1)
+
+
 def test_nd_utility_matches_reference(gp):
     """Active-learning utility: device kernel incl. Lambert W against the real
     reference's nd_utility (scipy Lambert W) on the G8 fixture -- values from 7e-8 to 6e7, entries
