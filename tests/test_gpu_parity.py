@@ -292,6 +292,60 @@ def test_pipelined_units_match_sequential(dev):
         e.close()
 
 
+def test_config3_64_cells_N4096_four_in_flight(dev):
+    """BASELINE configs[3] at its real size: 64 independent cells x N = 4096, d = 128 (rectangular 16 x 8 grid),
+    X shared, every cell its own receptive-field centre (theta), r, m and V, four cells in flight on four
+    contexts / streams -- what `bench.py --config cells64` times.  All 64 results are bit-identical to the
+    one-at-a-time driver; cells 0, 37 and 63 are checked against the oracle (1e-9 / 1e-6)."""
+    from gaussian_processes_amd import multi
+    from gaussian_processes_amd.engine import GPFitEngine
+    from gaussian_processes_amd import utils as gp
+    N, d, cells, depth = 4096, 128, 64, 4
+    grid = syn.grid_for(d)
+    Xh = T(syn.stimuli(N, d))
+    Xd = Xh.to(dev)
+    inputs = {}
+    for c in range(cells):
+        rc, mc = syn.cell_inputs(N, c)
+        th0 = {k: torch.tensor(v, dtype=torch.float64) for k, v in syn.theta0(c).items()}
+        C, mask = gp.localker(th0, UPPER, LOWER, grid)
+        assert bool(mask.all())
+        V = 0.5 * gp.acosker(th0, Xd, Xd, C=C)
+        inputs[c] = (T(rc).to(dev), T(mc).to(dev), V, syn.theta_eval(c))
+    engs = [GPFitEngine(N, d) for _ in range(depth)]
+    streams = [torch.cuda.Stream() for _ in engs]
+    torch.cuda.synchronize()
+
+    def eval_cell(c):
+        r, m, V, th = inputs[c]
+        o = engs[0].fit_eval(th, LOWER, UPPER, grid, Xd, r, m, V, LOGA, LAM0, want_vectors=False)
+        return [o["loss"]] + [o["grad"][k] for k in KEYS]
+
+    def submit(c, slot):
+        r, m, V, th = inputs[c]
+        with torch.cuda.stream(streams[slot]):
+            return engs[slot].fit_eval_async(th, LOWER, UPPER, grid, Xd, r, m, V, LOGA, LAM0, want_vectors=False)
+
+    def collect(t, slot):
+        o = engs[slot].fit_eval_finish(t)
+        return [o["loss"]] + [o["grad"][k] for k in KEYS]
+
+    pipe = multi.run_sharded(cells, None, dev, submit_fn=submit, collect_fn=collect, depth=depth)
+    seq = multi.run_sharded(cells, eval_cell, dev)
+    for e in engs:
+        e.close()
+    assert pipe.shape == (cells, 7) and torch.isfinite(pipe).all()
+    assert torch.equal(pipe, seq)
+    assert len({float(v) for v in pipe[:, 0]}) == cells            # 64 different cells, 64 different losses
+    table = pipe.cpu().numpy()
+    for c in (0, 37, 63):
+        r, m, V, th = inputs[c]
+        loss, grad = orc.mstep_closure_cholesky(th, LOWER, UPPER, grid, Xh, r.cpu(), m.cpu(), V.cpu(), LOGA, LAM0)
+        g = np.array([grad[k] for k in KEYS])
+        assert abs(table[c, 0] - loss) <= TOL_LOSS * abs(loss), (c, table[c, 0], loss)
+        assert np.abs(table[c, 1:] - g).max() <= TOL_GRAD * np.abs(g).max(), (c, table[c, 1:], g)
+
+
 def test_reuse_of_V_factor_is_exact(dev):
     """reuse_V=True (V constant during an M-step) must give bit-identical results."""
     grid, X, r, m, V, th1 = synthetic_case(384, 64)
