@@ -177,7 +177,8 @@ def main():
     ap.add_argument("--d", type=int, default=0, help="override d")
     ap.add_argument("--cells", type=int, default=64)
     ap.add_argument("--grid-points", type=int, default=512)
-    ap.add_argument("--depth", type=int, default=4, help="independent units kept in flight per GPU (cells64)")
+    ap.add_argument("--depth", type=int, default=None,
+                    help="independent units kept in flight per GPU (default: 4 cells for cells64, 3 theta points for thetagrid)")
     ap.add_argument("--cpu-sample-n", type=int, default=4096)
     ap.add_argument("--cpu-quick", action="store_true", help="skip the real N=8192 CPU evaluation (about 90 s)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -187,6 +188,9 @@ def main():
                          "(the theta-grid configuration's default: the all-fp32 instance misses the 1e-5 bar on part of "
                          "the lattice); f32 = every matrix in fp32")
     args = ap.parse_args()
+    args.depth_given = args.depth is not None
+    if args.depth is None:
+        args.depth = 3 if args.config == "thetagrid" else 4   # measured optima (scripts/dev_grid_depth.sh; cells: r01)
     dtype_name = args.dtype or ("mixed" if args.config == "thetagrid" else "f64")
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -280,14 +284,37 @@ def main():
         units_per_step, unit_name, scaling = npts, "theta-points", "strong"
         first = [True]
 
+        # points are independent: --depth of them are kept in flight on as many contexts / streams, so that one
+        # point's latency-bound Cholesky chain runs beside another's large gradient products (each context
+        # factors V once and then reuses its own copy of the factor)
+        tdepth = max(1, args.depth)
+        engs = [eng] + [GPFitEngine(N, d, device=local_rank) for _ in range(tdepth - 1)]
+        extra_engines = engs[1:]
+        streams = [torch.cuda.Stream(device=dev) for _ in engs]
+        fresh = [True] * len(engs)
+
         def eval_point(u):
             o = eng.fit_eval(points[u], lower, upper, grid, Xd, rd, md, Vd, logA, lam0, want_grad=want_grad,
                              want_vectors=False, reuse_V=not first[0], grad_precision=gprec)
             first[0] = False
             return [o["loss"]] + [o["grad"][k] for k in syn.THETA_KEYS]
 
+        def submit_point(u, slot):
+            with torch.cuda.stream(streams[slot]):
+                t = engs[slot].fit_eval_async(points[u], lower, upper, grid, Xd, rd, md, Vd, logA, lam0, want_grad=want_grad,
+                                              want_vectors=False, reuse_V=not fresh[slot], grad_precision=gprec)
+            fresh[slot] = False
+            return t
+
+        def collect_point(ticket, slot):
+            o = engs[slot].fit_eval_finish(ticket)
+            return [o["loss"]] + [o["grad"][k] for k in syn.THETA_KEYS]
+
         def step():
-            t = multi.run_sharded(npts, eval_point, dev)
+            if tdepth == 1:
+                t = multi.run_sharded(npts, eval_point, dev)
+            else:
+                t = multi.run_sharded(npts, None, dev, submit_fn=submit_point, collect_fn=collect_point, depth=tdepth)
             return {"loss": float(t[0, 0])}
 
     if rank == 0:
@@ -402,7 +429,8 @@ def main():
                     "cells64": f"{args.cells} independent cells x N={N} d={d} {dtype_name}, cyclic shard over the ranks, X broadcast once, "
                                f"{max(1, args.depth)} cells in flight per GPU (BASELINE configs[3])",
                     "thetagrid": f"{args.grid_points} theta points x N={N} d={d} {dtype_name} with gradients, cyclic shard over the ranks, "
-                                 f"X, r, m, V broadcast once, V factor reused across points (BASELINE configs[4])"}[args.config]
+                                 f"X, r, m, V broadcast once, V factor reused across points, {max(1, args.depth)} points in flight per GPU "
+                                 f"(BASELINE configs[4])"}[args.config]
         if not want_grad:
             workload += " [forward only]"
         out = {

@@ -131,6 +131,45 @@ def test_mixed_precision_small_and_ragged():
         assert b["loss"] == c2["loss"]
 
 
+def test_theta_points_in_flight_match_one_at_a_time():
+    """The theta-grid driver of bench.py keeps three points in flight on three contexts, each reusing its own
+    copy of the V factor (asynchronous entry point + reuse flag + mixed precision together): bit-identical to
+    the one-at-a-time sweep on one context."""
+    from gaussian_processes_amd import multi
+    from gaussian_processes_amd.engine import GPFitEngine
+    dev = torch.device("cuda:0")
+    N, d, depth = 1000, 64, 3
+    grid, X, r, m, V = case(N, d, dev)
+    points = syn.theta_grid(8)[::73][:7]
+    engs = [GPFitEngine(N, d) for _ in range(depth)]
+    streams = [torch.cuda.Stream() for _ in engs]
+    torch.cuda.synchronize()
+    row = lambda o: [o["loss"]] + [o["grad"][k] for k in KEYS]
+    for prec in ("native", "f32"):
+        fresh = [True] * depth
+        first = [True]
+
+        def one(u):
+            o = engs[0].fit_eval(points[u], LOWER, UPPER, grid, X, r, m, V, LOGA, LAM0, want_vectors=False,
+                                 reuse_V=not first[0], grad_precision=prec)
+            first[0] = False
+            return row(o)
+
+        def submit(u, slot):
+            with torch.cuda.stream(streams[slot]):
+                t = engs[slot].fit_eval_async(points[u], LOWER, UPPER, grid, X, r, m, V, LOGA, LAM0, want_vectors=False,
+                                              reuse_V=not fresh[slot], grad_precision=prec)
+            fresh[slot] = False
+            return t
+
+        seq = multi.run_sharded(len(points), one, dev)
+        pipe = multi.run_sharded(len(points), None, dev, submit_fn=submit,
+                                 collect_fn=lambda t, slot: row(engs[slot].fit_eval_finish(t)), depth=depth)
+        assert torch.isfinite(seq).all() and torch.equal(seq, pipe), prec
+    for e in engs:
+        e.close()
+
+
 def test_fp32_rejects_mixed_dtypes():
     from gaussian_processes_amd.engine import GPFitEngine
     dev = torch.device("cuda:0")
