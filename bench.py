@@ -120,6 +120,41 @@ def build_V(X, grid, th0, dev):
     return 0.5 * K
 
 
+def in_flight_rate(eng, N, d, X, grid, dev, tdt, lower, upper, logA, lam0, want_grad, gprec, local_rank, depth=3, cells=6, rounds=3):
+    """fits/s with `depth` independent cells of the headline size in flight (multi.evaluate_units_pipelined)."""
+    inputs = []
+    for c in range(cells):
+        rc, mc = syn.cell_inputs(N, c)
+        inputs.append((torch.from_numpy(rc).to(dev).to(tdt), torch.from_numpy(mc).to(dev).to(tdt),
+                       build_V(X, grid, syn.theta0(c), dev).to(tdt), syn.theta_eval(c)))
+    Xd = X.to(tdt)
+    engs = [eng] + [GPFitEngine(N, d, device=local_rank) for _ in range(depth - 1)]
+    streams = [torch.cuda.Stream(device=dev) for _ in engs]
+
+    def submit(u, slot):
+        rc, mc, Vc, thc = inputs[u % cells]
+        with torch.cuda.stream(streams[slot]):
+            return engs[slot].fit_eval_async(thc, lower, upper, grid, Xd, rc, mc, Vc, logA, lam0, want_grad=want_grad,
+                                             want_vectors=False, grad_precision=gprec)
+
+    def collect(t, slot):
+        o = engs[slot].fit_eval_finish(t)
+        return [o["loss"]] + [o["grad"][k] for k in syn.THETA_KEYS]
+
+    units = list(range(cells * rounds))
+    multi.evaluate_units_pipelined(units[:cells], submit, collect, dev, depth)          # warm-up
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    table = multi.evaluate_units_pipelined(units, submit, collect, dev, depth)
+    torch.cuda.synchronize(dev)
+    dt = time.perf_counter() - t0
+    for e in engs[1:]:
+        e.close()
+    assert bool(torch.isfinite(table).all())
+    return {"fits_per_s": round(len(units) / dt, 3), "ms_per_fit": round(dt / len(units) * 1e3, 3), "in_flight": depth,
+            "what": f"{len(units)} evaluations of {cells} independent cells of the headline size, {depth} in flight on {depth} contexts"}
+
+
 def cpu_reference_eval(n, d, repeats, do_cholesky=True):
     """Reference-formulation closure (oracle.mstep_closure_reference: materialised dK{6},
     eigen-projection, LU inverse, 13+13 GEMM gradient products; torch CPU fp64) on the host cores of
@@ -182,6 +217,7 @@ def main():
     ap.add_argument("--cpu-sample-n", type=int, default=4096)
     ap.add_argument("--cpu-quick", action="store_true", help="skip the real N=8192 CPU evaluation (about 90 s)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-in-flight", action="store_true", help="skip the informational leg with independent cells in flight")
     ap.add_argument("--no-grad", action="store_true", help="forward-only unit (not the headline metric)")
     ap.add_argument("--dtype", choices=["f64", "f32", "mixed"], default=None,
                     help="f64 = the reference's precision; mixed = fp64 factorisations and loss, fp32 gradient products "
@@ -445,6 +481,12 @@ def main():
             "loss": res["loss"],
             "roofline": roofline,
         }
+        if world == 1 and args.config == "headline" and not args.no_in_flight:
+            # Beside `value` (evaluations of ONE cell, each waiting for the previous one, as an L-BFGS closure does):
+            # what the same GPU delivers when the evaluations are independent (several cells of this size, as in
+            # configs[3]) and three are kept in flight on three contexts.  Informational, never `value`.
+            out["independent_units_in_flight"] = in_flight_rate(eng, N, d, X, grid, dev, tdt, lower, upper, logA, lam0,
+                                                                want_grad, gprec, local_rank)
         if world == 1 and not args.no_cpu_baseline and dtype_name == "f64" and args.config == "headline":
             cores, small, full = cpu_baseline(N, d, min(args.cpu_sample_n, N), args.cpu_quick)
             scale = (N / small["n"]) ** 3

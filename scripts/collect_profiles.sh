@@ -10,10 +10,10 @@ python bench.py > $out/${tag}_bench_full.json 2> $out/${tag}_bench_full.err
 python bench.py --dtype f32 --no-cpu-baseline > $out/${tag}_bench_f32.json 2>/dev/null
 python bench.py --dtype mixed --no-cpu-baseline > $out/${tag}_bench_mixed.json 2>/dev/null
 rm -rf $out/${tag}_kt $out/${tag}_pmcf $out/${tag}_pmcw $out/${tag}_pmcm
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_kt -- python bench.py --steps 5 --warmup 1 --no-cpu-baseline > $out/${tag}_kt.log 2>&1
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/${tag}_pmcf -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline > $out/${tag}_pmcf.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/${tag}_pmcw -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline > $out/${tag}_pmcw.log 2>&1
-rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $out/${tag}_pmcm -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline > $out/${tag}_pmcm.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_kt -- python bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-in-flight > $out/${tag}_kt.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/${tag}_pmcf -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-in-flight > $out/${tag}_pmcf.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/${tag}_pmcw -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-in-flight > $out/${tag}_pmcw.log 2>&1
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $out/${tag}_pmcm -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-in-flight > $out/${tag}_pmcm.log 2>&1
 # keep only what refresh_profiles.py reads (the raw traces are large)
 find $out/${tag}_kt -name "*kernel_trace.csv" -delete
 : > $out/${tag}_configs.jsonl

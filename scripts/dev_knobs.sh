@@ -4,5 +4,5 @@
 cd "$GRAFT_REPO_ROOT" || exit 1
 for kv in "$@"; do
   echo "[$kv]"
-  env $kv python bench.py --steps 20 --warmup 3 --no-cpu-baseline 2>/dev/null | python -c "import json,sys; j=json.loads(sys.stdin.read()); print(j['ms_per_step'], j['roofline']['phases_ms'])"
+  env $kv python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-in-flight 2>/dev/null | python -c "import json,sys; j=json.loads(sys.stdin.read()); print(j['ms_per_step'], j['roofline']['phases_ms'])"
 done
