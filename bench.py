@@ -422,7 +422,12 @@ def main():
                     "fp32 peak and therefore understates the fp64 half",
             "achieved": round(dom_tflops, 2), "peak": peak, "unit": "TFLOP/s",
             "frac": round(dom_tflops / peak, 4),
-            "traffic": profiled_traffic(dom_name, blocks=None) if dtype_name == "f64" else None,
+            # HBM-side bytes per launch (fetch with the gfx950 correction + write) from the committed PMC passes; the
+            # algorithmic operand bytes of the launch are 3 N^2 / 2 x 8 B (two triangular inputs, one triangular output)
+            "traffic": (lambda t: None if t is None else round((t["fetch_corrected"] + t["write"]) * 1e9))(
+                profiled_traffic(dom_name, blocks=None) if dtype_name == "f64" else None),
+            "traffic_detail": profiled_traffic(dom_name, blocks=None) if dtype_name == "f64" else None,
+            "algorithmic_bytes_per_launch": 1.5 * float(npad) ** 2 * (8 if dtype_name == "f64" else 4),
             "mfma_util": util,
             "launches_per_fit": 1, "avg_launch_ms": round(prof["largest_gemm_ms"], 4),
             "algorithmic_flops_per_launch": dom_flops,

@@ -1,0 +1,28 @@
+"""Time split of eigtop.top_eigenpairs on the bench kernel matrix (wraps the primitives with synchronised timers)."""
+import os, sys, time, collections
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from gaussian_processes_amd import utils as gp, synthetic as syn, eigtop
+import bench
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
+dev = torch.device("cuda:0")
+X = torch.from_numpy(syn.stimuli(N, 256)).to(dev)
+K = 2.0 * bench.build_V(X, syn.grid_for(256), syn.theta0(), dev)
+acc = collections.defaultdict(lambda: [0, 0.0])
+def timed(name, fn):
+    def w(*a, **k):
+        torch.cuda.synchronize(); t0 = time.perf_counter(); r = fn(*a, **k); torch.cuda.synchronize()
+        acc[name][0] += 1; acc[name][1] += time.perf_counter() - t0; return r
+    return w
+def mm(A, B, **k):
+    key = f"matmul {tuple(A.shape)}{'T' if k.get('transA') else ''} x {tuple(B.shape)}{'T' if k.get('transB') else ''}"
+    return timed(key, gp.matmul)(A, B, **k)
+chol = timed("cholesky+inverse", gp.cholesky)
+orig_eigh = torch.linalg.eigh
+torch.linalg.eigh = timed("eigh (k x k)", orig_eigh)
+eigtop.top_eigenpairs(K, 1e-4, gp.matmul, gp.cholesky)          # warm-up
+acc.clear()
+t0 = time.perf_counter(); out = eigtop.top_eigenpairs(K, 1e-4, mm, chol); torch.cuda.synchronize(); tot = time.perf_counter() - t0
+print(f"N={N}: total {tot*1e3:.1f} ms (with per-call synchronisation), info {out[2]}")
+for k, (n, t) in sorted(acc.items(), key=lambda kv: -kv[1][1]):
+    print(f"  {k:60s} n {n:3d} total {t*1e3:7.1f} ms  avg {t/n*1e3:6.2f} ms")
