@@ -199,6 +199,20 @@ def test_headline_N8192_matches_oracle(dev, headline):
     assert_close(res, loss, p["loglik"], p["KL"], grad, p["lam_m"], p["lam_var"], p["f"])
 
 
+def test_large_ragged_N7100_matches_oracle(dev):
+    """A large size that is NOT a multiple of the 128-tile (N = 7100 -> padded to 7168, 1596 lower tiles: just
+    over the threshold of the XCD-aware schedule, so T and Q run on the schedule tables with their fused
+    epilogues over a padded last tile row) against the oracle, same tolerances as everywhere else; d = 225
+    (15 x 15 pixels, not a multiple of the K step either)."""
+    N, d = 7100, 225
+    grid, X, r, m, V, th1 = synthetic_case(N, d)
+    torch.set_num_threads(max(1, min(32, len(__import__("os").sched_getaffinity(0)))))
+    loss, grad, p = orc.mstep_closure_cholesky(th1, LOWER, UPPER, grid, X, r, m, V, LOGA, LAM0, want_parts=True)
+    res = gpu_eval(dev, th1, grid, X, r, m, V)
+    assert_close(res, loss, p["loglik"], p["KL"], grad, p["lam_m"], p["lam_var"], p["f"])
+    _ENGINES.pop((N, d, d)).close()
+
+
 def test_headline_gradient_matches_finite_difference(dev, headline):
     """Directional derivative of the loss along a fixed direction vs central differences.
     (The reference's analytic dK ignores the +1e-7 and the clip in cos(delta), utils.py:984 vs
