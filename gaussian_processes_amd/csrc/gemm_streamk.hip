@@ -110,17 +110,30 @@ template <typename R>
 __global__ __launch_bounds__(256) void streamk_fixup_kernel(SkParams<R> p, const int* __restrict__ fix_tile,
                                                             const int* __restrict__ fix_ptr,
                                                             const int* __restrict__ fix_slot) {
-  // grid = (split tiles, 8): each workgroup sums a 16-row band, so that a launch with few split
-  // tiles but many partials per tile (short tails) still spreads over the chip
+  // grid = (split tiles, 32): each workgroup sums a 4-row band (two elements per thread as one 16-byte access
+  // in fp64), so that a launch with few split tiles but many partials per tile (short tails) still spreads over
+  // the chip; the partials of an element are loaded four at a time and added in plan order (the latency of
+  // the loads overlaps, the order of the additions -- hence the bits of the result -- does not change)
+  using V = typename Real<R>::vec_t;
+  constexpr int EPC = Real<R>::EPC;
   const SkTile tl = p.tiles[fix_tile[blockIdx.x]];
   const int s0 = fix_ptr[blockIdx.x], s1 = fix_ptr[blockIdx.x + 1];
   const R alpha = (R)p.alpha, beta = (R)p.beta;
   const int band = TILE / (int)gridDim.y;
-  for (int e = threadIdx.x; e < band * TILE; e += blockDim.x) {
+  for (int e = threadIdx.x * EPC; e < band * TILE; e += blockDim.x * EPC) {
     const int r = blockIdx.y * band + (e >> 7), c = e & 127;
-    R sum = 0;
-    for (int s = s0; s < s1; ++s) sum += p.partial[(int64_t)fix_slot[s] * (TILE * TILE) + r * TILE + c];
-    R* cp = p.C + (int64_t)(tl.row0 + r) * p.ldc + tl.col0 + c;
+    const int64_t off = (int64_t)r * TILE + c;
+    V sum = V{};
+    int s = s0;
+    for (; s + 4 <= s1; s += 4) {
+      const V v0 = *reinterpret_cast<const V*>(p.partial + (int64_t)fix_slot[s] * (TILE * TILE) + off);
+      const V v1 = *reinterpret_cast<const V*>(p.partial + (int64_t)fix_slot[s + 1] * (TILE * TILE) + off);
+      const V v2 = *reinterpret_cast<const V*>(p.partial + (int64_t)fix_slot[s + 2] * (TILE * TILE) + off);
+      const V v3 = *reinterpret_cast<const V*>(p.partial + (int64_t)fix_slot[s + 3] * (TILE * TILE) + off);
+      sum += v0; sum += v1; sum += v2; sum += v3;
+    }
+    for (; s < s1; ++s) sum += *reinterpret_cast<const V*>(p.partial + (int64_t)fix_slot[s] * (TILE * TILE) + off);
+    V* cp = reinterpret_cast<V*>(p.C + (int64_t)(tl.row0 + r) * p.ldc + tl.col0 + c);
     *cp = (beta == (R)0) ? alpha * sum : alpha * sum + beta * (*cp);
   }
 }
@@ -291,7 +304,7 @@ int launch_gemm_streamk(const GemmArgsT<R>& a, hipStream_t s) {
     case 3: hipLaunchKernelGGL((gemm_streamk_kernel<R, true, true>), grid, block, 0, s, p); break;
   }
   if (plan.nfix)
-    hipLaunchKernelGGL(streamk_fixup_kernel<R>, dim3(plan.nfix, 8), dim3(256), 0, s, p, plan.fix_tile, plan.fix_ptr,
+    hipLaunchKernelGGL(streamk_fixup_kernel<R>, dim3(plan.nfix, 32), dim3(256), 0, s, p, plan.fix_tile, plan.fix_ptr,
                        plan.fix_slot);
   GP_HIP(hipGetLastError());
   return 0;
