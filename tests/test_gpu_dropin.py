@@ -54,6 +54,53 @@ def test_matmul_and_cholesky_primitives(gp):
         assert relerr(gp.spd_inverse(S).cpu().numpy(), torch.linalg.inv(S).numpy()) < 1e-10
 
 
+def test_dgemm_flag_combinations_at_recursion_sizes(gp):
+    """gpfit_dgemm_ex at the sizes of the bottom of the Cholesky recursion (128, 256, mixed, and a ragged one):
+    every operand layout, triangular flags on exactly triangular operands, lower-only output, alpha / beta --
+    against torch within rounding, and the tile the launcher picks against the 32-tile instance forced through
+    `tile` bit for bit (every instance walks k upwards in steps of four)."""
+    from gaussian_processes_amd import _lib
+    lib = _lib.load()
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(3)
+    st = torch.cuda.current_stream().cuda_stream
+
+    def run(tile, ak, bk, M, N, K, alpha, A, B, beta, C0, lower, at, bt):
+        C = C0.clone()
+        rc = lib.gpfit_dgemm_ex(st, ak, bk, M, N, K, alpha, A.data_ptr(), A.stride(0), B.data_ptr(), B.stride(0), beta,
+                                C.data_ptr(), C.stride(0), lower, at, bt, 0, tile)
+        assert rc == 0
+        return C
+
+    for (M, N, K) in ((128, 128, 128), (256, 256, 256), (256, 128, 128), (128, 256, 256), (64, 48, 32)):
+        for ak in (0, 1):
+            for bk in (0, 1):
+                for at, bt, lower in ((0, 0, 0), (1, 1, 0), (2, 0, 0), (0, 2, 0), (1, 2, 1), (0, 0, 1), (2, 1, 0)):
+                    if lower and M != N:
+                        continue
+                    if (at and M != K) or (bt and N != K):
+                        continue
+                    opA = torch.randn(M, K, dtype=torch.float64, generator=g)
+                    opB = torch.randn(K, N, dtype=torch.float64, generator=g)
+                    if at == 1: opA = torch.tril(opA)
+                    if at == 2: opA = torch.triu(opA)
+                    if bt == 1: opB = torch.tril(opB)
+                    if bt == 2: opB = torch.triu(opB)
+                    A = (opA.T.contiguous() if ak else opA.contiguous()).to(dev)     # ak: stored [K][M]
+                    B = (opB.contiguous() if bk else opB.T.contiguous()).to(dev)     # bk: stored [K][N]
+                    C0 = torch.randn(M, N, dtype=torch.float64, generator=g).to(dev)
+                    for alpha, beta in ((1.0, 0.0), (-0.5, 1.0)):
+                        new = run(0, ak, bk, M, N, K, alpha, A, B, beta, C0, lower, at, bt)
+                        ref = alpha * (opA @ opB) + beta * C0.cpu()
+                        if lower:   # 128-blocks strictly above the block diagonal are left alone
+                            blk = (torch.arange(M)[:, None] // 128) >= (torch.arange(N)[None, :] // 128)
+                            ref = torch.where(blk, ref, C0.cpu())
+                        assert relerr(new.cpu().numpy(), ref.numpy()) < 1e-13, (M, N, K, ak, bk, at, bt, lower)
+                        if M % 32 == 0 and N % 32 == 0:
+                            old = run(32, ak, bk, M, N, K, alpha, A, B, beta, C0, lower, at, bt)
+                            assert torch.equal(new, old), (M, N, K, ak, bk, at, bt, lower, alpha, beta)
+
+
 def test_log_det_fallbacks(gp):
     M = torch.diag(torch.tensor([4.0, -1.0, 2.0], dtype=torch.float64))
     with warnings.catch_warnings(record=True) as w:
