@@ -101,6 +101,38 @@ def test_dgemm_flag_combinations_at_recursion_sizes(gp):
                             assert torch.equal(new, old), (M, N, K, ak, bk, at, bt, lower, alpha, beta)
 
 
+def test_g7_known_answers_of_the_reference_notebook_on_the_gpu_functions(gp):
+    """The reference's only known-answer check (moments_gradients.ipynb): its hand-written
+    3 x 3 / 3 x 4 tensors through the drop-in lambda_moments / compute_loglikelihood / compute_KL_div
+    themselves (the oracle passes the same check on the CPU): d lambda_m, d lambda_var, logLK = 41,
+    dlogLK = 127749.63888888987, dKL = 110.47222222222383 -- the saved outputs of the notebook."""
+    a_mat = T([[1., 2, 3, 4], [5, 6, 7, 8], [9, 10, 11, 12]])
+    Sigma = T([[1., 2, 3], [5, 6, 7], [8, 7, 6]]); Sigma = Sigma + Sigma.T
+    dSigma = T([[4., 5, 6], [5, 6, 7], [6, 7, 8]]); dSigma = dSigma + dSigma.T
+    m = T([1., 2, 3])
+    dki = T([[6., 7, 8, 9], [2, 3, 4, 5], [9, 8, 7, 6]])
+    dkstar = T([3., 4, 5, 6])
+    a, K, dK = a_mat.T.contiguous(), dki.T.contiguous(), dki.T.contiguous()
+    Kt_inv = torch.linalg.pinv(Sigma)
+    V = torch.linalg.inv(Sigma * 3)
+    lam_m, lam_var, dlm, dlv = gp.lambda_moments(None, Sigma, a, torch.zeros(4, dtype=torch.float64), K, None, m, V, None,
+                                                 dK={"p": dK}, dK_tilde={"p": dSigma}, dK_vec={"p": dkstar},
+                                                 K_tilde_inv=Kt_inv)
+    assert np.allclose(dlm["p"].cpu().numpy(), [13.75, 19.9167, 26.0833, 32.25], atol=5e-5)
+    assert np.allclose(dlv["p"].cpu().numpy(), [-2199.1944, -3161.6944, -4291.75, -5589.3611], atol=5e-5)
+    f = T([55., 4, 22, 5]); r = T([23., 47, 2, 1])
+    fp = {"logA": torch.tensor(0.0, dtype=torch.float64), "lambda0": torch.tensor(0.0, dtype=torch.float64)}
+    L, dL = gp.compute_loglikelihood(r, f, T([1., 2, 3, 4]), lam_var, fp, dlambda_m=dlm, dlambda_var=dlv)
+    assert float(L) == 41.0
+    assert abs(float(dL["p"]) - 127749.63888888987) < 1e-6
+    # the gradient line of compute_KL_div (utils.py:1331-1333) on the notebook's matrices (Sigma is indefinite, so
+    # its log-determinant terms are taken on the shifted matrices there; the gradient does not involve them)
+    c, b = gp.matmul(V, Kt_inv), gp.matmul(Kt_inv, m)
+    Bk = gp.matmul(dSigma, Kt_inv)
+    dKL = 0.5 * torch.trace(Bk) - 0.5 * torch.sum(c * Bk.T) - 0.5 * torch.dot(b, gp.matmul(Bk, m))
+    assert abs(float(dKL) - 110.47222222222383) < 1e-9
+
+
 def test_log_det_fallbacks(gp):
     M = torch.diag(torch.tensor([4.0, -1.0, 2.0], dtype=torch.float64))
     with warnings.catch_warnings(record=True) as w:
