@@ -821,6 +821,54 @@ def test_closure_in_the_subspace_basis_equals_the_eigh_basis(gp):
     assert np.abs(g0 - g1).max() <= 1e-8 * np.abs(g1).max(), (g0, g1)
 
 
+def test_vargp_with_the_subspace_basis_tracks_the_eigh_route(gp):
+    """A whole fit at the reference's default tolerance at N = 4096 (about 520 of 4096 directions kept, the
+    count moving with theta from one EM iteration to the next), once with the kept eigenpairs from the
+    subspace solver and once with torch.linalg.eigh forced: same kept counts, log-marginal track to 1e-8, final
+    theta to 1e-7, predictions to 1e-7 (eigenvector signs differ between the two routes; nothing downstream
+    depends on them)."""
+    N, d = 4096, 256
+    dev = torch.device("cuda:0")
+    X = T(syn.stimuli(N, d)).to(dev)
+    r = T(syn.cell_inputs(N, 3)[0]).to(dev)
+    rng = np.random.default_rng(11)
+    Xs = T(rng.standard_normal((12, 16, 16, 1))).to(dev)
+    Rt = T(rng.poisson(0.7, (4, 12, 1)).astype(np.float64)).to(dev)
+
+    def run(force):
+        th = {k: torch.tensor(float(v), dtype=torch.float64, requires_grad=True) for k, v in syn.theta0(3).items()}
+        fp = {"ntilde": N, "maxiter": 3, "nEstep": 2, "nMstep": 4, "nFparamstep": 3, "kernfun": "acosker", "cellid": 0,
+              "n_px_side": 16, "display_hyper": False}
+        args = {"fit_parameters": fp, "xtilde": X, "hyperparams_tuple": (th, LOWER, UPPER),
+                "f_params": {"logA": torch.tensor(syn.F_PARAMS["logA"], dtype=torch.float64, requires_grad=True),
+                             "lambda0": torch.tensor(syn.F_PARAMS["lambda0"], dtype=torch.float64)}}
+        old = gp._FORCE_EIGH
+        gp._FORCE_EIGH = force
+        gp._LAST_REGIME.clear()
+        try:
+            with contextlib.redirect_stdout(io.StringIO()), warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                fit, err = gp.varGP(X, r, **args)
+                _, R_pred, _, _ = gp.test(Xs, Rt, X_train=X, at_iteration=None, **fit)
+                _, R_it1, _, _ = gp.test(Xs, Rt, X_train=X, at_iteration=1, **fit)
+        finally:
+            gp._FORCE_EIGH = old
+        assert not err["is_error"], err
+        return fit, R_pred, R_it1
+
+    a, Ra, Ra1 = run(False)
+    b, Rb, Rb1 = run(True)
+    assert a["B"].shape == b["B"].shape and 100 < a["B"].shape[1] < N // 4
+    la, lb = a["values_track"]["loss_track"]["logmarginal"].numpy(), b["values_track"]["loss_track"]["logmarginal"].numpy()
+    assert relerr(la, lb) < 1e-8, (la, lb)
+    ta = np.array([float(a["hyperparams_tuple"][0][k]) for k in KEYS]); tb = np.array([float(b["hyperparams_tuple"][0][k]) for k in KEYS])
+    assert np.abs(ta - tb).max() < 1e-7
+    assert relerr(Ra.cpu().numpy(), Rb.cpu().numpy()) < 1e-7
+    # test(at_iteration=1) rebuilds the basis from the tracked theta: the solver returns the basis the tracked
+    # (m_b, V_b) were expressed in (deterministic start block and sign convention)
+    assert relerr(Ra1.cpu().numpy(), Rb1.cpu().numpy()) < 1e-7
+
+
 def test_nd_utility_matches_reference(gp):
     """Active-learning utility: device kernel incl. Lambert W against the real
     reference's nd_utility (scipy Lambert W) on the G8 fixture -- values from 7e-8 to 6e7, entries
