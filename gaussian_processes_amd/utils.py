@@ -1375,3 +1375,24 @@ def test(X_test, R_test, xtilde, X_train=None, at_iteration=None, **kwargs):
     print(f"\n\n Pietro's model: R2 = {float(r2):.2f} ± {float(sigma_r2):.2f} Cell: {cellid} maxiter = {maxiter}, "
           f"nEstep = {nEstep}, nMstep = {nMstep} \n")
     return R_test[:, :, cellid], R_predicted, r2, sigma_r2
+
+
+# ------------------------------------------------------------------ names of the reference that are not provided
+_NOT_PROVIDED = {
+    "plot_loss_and_theta_notebook": "plotting helper (utils.py:111): call the reference's own function on the fit_model dict "
+                                    "this module returns -- the schema is the same",
+    "plot_fit": "plotting helper (utils.py:1543)",
+    "save_pickle": "writes into the reference's own data/ directory (utils.py:689)",
+    "utility": "scalar form of nd_utility (utils.py:596): use nd_utility, which accepts 0-d inputs",
+    "get_utility": "no caller in the reference, and its own call of lambda_moments_star does not match that function's signature (utils.py:619-629)",
+    "block_matrix_inverse": "no caller in the reference (utils.py:1055); cholesky_append is the rank-1 update of this module",
+    "updateA": "no caller in the reference (utils.py:1339)",
+    "linker": "no caller in the reference (utils.py:916)",
+}
+
+
+def __getattr__(name):
+    if name in _NOT_PROVIDED:
+        raise AttributeError(f"gaussian_processes_amd.utils does not provide {name!r}: {_NOT_PROVIDED[name]} "
+                             "(out of the scope of the fit path, DESIGN.md section 8)")
+    raise AttributeError(f"module {__name__!r} has no attribute {name!r}")

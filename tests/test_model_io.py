@@ -36,3 +36,15 @@ def test_round_trip_layout_and_refusal(tmp_path):
     assert isinstance(back["hyperparams_tuple"], tuple)
     with pytest.raises(ValueError, match="already exists"):
         model_io.save_model(model, target)
+
+
+def test_out_of_scope_names_say_why():
+    """Names of the reference's utils.py that this module leaves out raise an AttributeError that says so
+    (a notebook cell calling the plotting helper gets an explanation, not a bare failure)."""
+    pytest.importorskip("torch")
+    from gaussian_processes_amd import utils as gp
+    with pytest.raises(AttributeError, match="plotting helper"):
+        gp.plot_loss_and_theta_notebook
+    with pytest.raises(AttributeError, match="no attribute"):
+        gp.definitely_not_a_name
+    assert callable(gp.save_model) and callable(gp.load_model) and callable(gp.nd_utility)
