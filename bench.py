@@ -213,7 +213,7 @@ def main():
     ap.add_argument("--cells", type=int, default=64)
     ap.add_argument("--grid-points", type=int, default=512)
     ap.add_argument("--depth", type=int, default=None,
-                    help="independent units kept in flight per GPU (default: 4 cells for cells64, 3 theta points for thetagrid)")
+                    help="independent units kept in flight per GPU (default: 3 for cells64 and thetagrid)")
     ap.add_argument("--cpu-sample-n", type=int, default=4096)
     ap.add_argument("--cpu-quick", action="store_true", help="skip the real N=8192 CPU evaluation (about 90 s)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -226,7 +226,7 @@ def main():
     args = ap.parse_args()
     args.depth_given = args.depth is not None
     if args.depth is None:
-        args.depth = 3 if args.config == "thetagrid" else 4   # measured optima (scripts/dev_grid_depth.sh; cells: r01)
+        args.depth = 3   # measured optimum for both configs this round (cells64: 148 / 183 / 168 / 166 / 168 cells/s at 2..6)
     dtype_name = args.dtype or ("mixed" if args.config == "thetagrid" else "f64")
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
