@@ -1,0 +1,82 @@
+"""The block subspace eigensolver of the truncated regime (gaussian_processes_amd/eigtop.py) is written against two
+callables, a GEMM and a Cholesky-with-inverse; here it runs on torch CPU stand-ins for them, so its logic (block
+growth, sweep prediction, residual certificate, refusals, determinism, sign convention) is covered without a GPU.
+The GPU suite runs the same function on the library's own primitives (tests/test_gpu_dropin.py)."""
+import numpy as np
+import torch
+
+from gaussian_processes_amd import eigtop
+
+
+def cpu_matmul(A, B, transA=False, transB=False):
+    return (A.T if transA else A) @ (B.T if transB else B)
+
+
+def cpu_cholesky(M, want_inverse=False):
+    L, info = torch.linalg.cholesky_ex(M)
+    if int(info) != 0:
+        return None, None, 0.0, int(info)
+    Li = torch.linalg.solve_triangular(L, torch.eye(M.shape[0], dtype=M.dtype), upper=False)
+    return L, Li, float(2 * torch.log(torch.diagonal(L)).sum()), 0
+
+
+def kernel_like_matrix(n, seed=0):
+    """SPD matrix with a spectrum like the arc-cosine kernel matrices of the fit: a few large eigenvalues, a
+    smooth decay through the threshold, no gap at it."""
+    g = torch.Generator().manual_seed(seed)
+    Q, _ = torch.linalg.qr(torch.randn(n, n, dtype=torch.float64, generator=g))
+    lam = 1e5 * (1.0 + torch.arange(n, dtype=torch.float64)) ** -2.2 + 1e-3
+    return (Q * lam) @ Q.T, lam, Q
+
+
+def test_subspace_solver_matches_eigh_on_cpu_primitives():
+    n, tol = 900, 1e-4
+    K, lam, Q = kernel_like_matrix(n)
+    K = (K + K.T) / 2
+    w, U = torch.linalg.eigh(K)
+    keep = w > max(float(w[-1]) * tol, tol)
+    out = eigtop.top_eigenpairs(K, tol, cpu_matmul, cpu_cholesky, k0=128)
+    assert out is not None
+    vals, vecs, info = out
+    assert 10 < int(keep.sum()) < n // 3 and vals.shape[0] == int(keep.sum())
+    assert float(((vals - w[keep]).abs() / w[keep]).max()) < 1e-10
+    P = U[:, keep].T @ vecs
+    eye = torch.eye(P.shape[0], dtype=torch.float64)
+    assert float((P.T @ P - eye).abs().max()) < 1e-9
+    assert float((vecs.T @ vecs - eye).abs().max()) < 1e-12
+    assert bool((vecs.abs().max(0).values == vecs.max(0).values).all())         # largest component positive
+    again = eigtop.top_eigenpairs(K, tol, cpu_matmul, cpu_cholesky, k0=128)
+    assert torch.equal(again[0], vals) and torch.equal(again[1], vecs)           # deterministic in K
+    assert info["k"] >= vals.shape[0] and info["rr"] >= 1
+
+
+def test_subspace_solver_grows_its_block_and_declines_when_too_much_is_kept():
+    n = 900
+    K, lam, Q = kernel_like_matrix(n, seed=1)
+    K = (K + K.T) / 2
+    w = torch.linalg.eigvalsh(K)
+    # a start block smaller than the kept count: the solver has to grow it
+    tol = 1e-4
+    n_keep = int((w > max(float(w[-1]) * tol, tol)).sum())
+    out = eigtop.top_eigenpairs(K, tol, cpu_matmul, cpu_cholesky, k0=max(8, n_keep // 2))
+    assert out is not None and out[0].shape[0] == n_keep and out[2]["grown"] >= 1
+    # a rule that keeps more than a third of the spectrum is left to the full eigendecomposition
+    tol = 1e-8
+    assert int((w > max(float(w[-1]) * tol, tol)).sum()) > n // 3
+    assert eigtop.top_eigenpairs(K, tol, cpu_matmul, cpu_cholesky, k0=128) is None
+
+
+def test_subspace_solver_declines_an_ambiguous_count():
+    """An eigenvalue sitting on the threshold within its residual: the count cannot be certified."""
+    n = 600
+    g = torch.Generator().manual_seed(2)
+    Q, _ = torch.linalg.qr(torch.randn(n, n, dtype=torch.float64, generator=g))
+    lam = 1e4 * (1.0 + torch.arange(n, dtype=torch.float64)) ** -2.0 + 1e-3
+    tol = 1e-3
+    lam[40] = float(lam[0]) * tol * (1 + 1e-14)                  # exactly at lambda_max * tol (to rounding)
+    K = (Q * lam) @ Q.T
+    K = (K + K.T) / 2
+    out = eigtop.top_eigenpairs(K, tol, cpu_matmul, cpu_cholesky, k0=128, max_sweeps=24)
+    w = torch.linalg.eigvalsh(K)
+    if out is not None:      # rounding put it clearly on one side: then the count must agree with eigh's
+        assert out[0].shape[0] == int((w > max(float(w[-1]) * tol, tol)).sum())
