@@ -213,6 +213,46 @@ def test_large_ragged_N7100_matches_oracle(dev):
     _ENGINES.pop((N, d, d)).close()
 
 
+def test_four_times_the_headline_N32768_is_self_consistent(dev):
+    """N = 32768 (112 GB of workspace of the 288 GB; every 64-bit index path, 32 896 tiles per triangular
+    launch): far beyond what the CPU oracle can check, so size-independent properties instead -- the analytic
+    directional derivative against central differences of the loss, the trace identity
+    KL = -1/2 log|V| + 1/2 log|K~| + 1/2 m.b + 1/2 tr(K~^-1 V) with V = K~(theta0)/2 evaluated AT theta0
+    (tr = N/2, log|V| = log|K~| - N log 2), and bit-identical repetition."""
+    from gaussian_processes_amd.engine import GPFitEngine
+    from gaussian_processes_amd import utils as gp
+    N, d = 32768, 256
+    grid = syn.grid_for(d)
+    X = T(syn.stimuli(N, d)).to(dev)
+    r_np, m_np = syn.cell_inputs(N)
+    r, m = T(r_np).to(dev), T(m_np).to(dev)
+    th0 = syn.theta0()
+    t0 = {k: torch.tensor(v, dtype=torch.float64) for k, v in th0.items()}
+    C, mask = gp.localker(t0, UPPER, LOWER, grid)
+    V = gp.acosker(t0, X, X, C=C)
+    V *= 0.5
+    eng = GPFitEngine(N, d)
+    at0 = eng.fit_eval(th0, LOWER, UPPER, grid, X, r, m, V, LOGA, LAM0, want_vectors=False)
+    # V = K~/2 at theta0: tr(K~^-1 V) = N/2 and log|V| = log|K~| - N log 2
+    assert abs((at0["logdet_K"] - at0["logdet_V"]) - N * np.log(2.0)) <= 1e-9 * N
+    assert abs(at0["tr_KinvV"] - 0.5 * N) <= 1e-8 * N and at0["mKinvm"] > 0
+    assert abs(at0["KL"] - 0.5 * (at0["logdet_K"] - at0["logdet_V"] + at0["mKinvm"] + at0["tr_KinvV"])) <= 1e-9 * abs(at0["KL"])
+    th1 = syn.theta_eval()
+    base = eng.fit_eval(th1, LOWER, UPPER, grid, X, r, m, V, LOGA, LAM0, want_vectors=False, reuse_V=True)
+    again = eng.fit_eval(th1, LOWER, UPPER, grid, X, r, m, V, LOGA, LAM0, want_vectors=False, reuse_V=True)
+    assert base["loss"] == again["loss"] and base["grad"] == again["grad"]
+    direction = {"sigma_0": 0.3, "eps_0x": -0.5, "eps_0y": 0.4, "-2log2beta": 0.2, "-log2rho2": -0.3, "Amp": 0.6}
+    h = 1e-5
+    lp = eng.fit_eval({k: th1[k] + h * direction[k] for k in KEYS}, LOWER, UPPER, grid, X, r, m, V, LOGA, LAM0,
+                      want_grad=False, want_vectors=False, reuse_V=True)["loss"]
+    lm = eng.fit_eval({k: th1[k] - h * direction[k] for k in KEYS}, LOWER, UPPER, grid, X, r, m, V, LOGA, LAM0,
+                      want_grad=False, want_vectors=False, reuse_V=True)["loss"]
+    fd = (lp - lm) / (2 * h)
+    an = sum(base["grad"][k] * direction[k] for k in KEYS)
+    eng.close()
+    assert abs(fd - an) <= 5e-5 * abs(an), (fd, an)
+
+
 def test_headline_gradient_matches_finite_difference(dev, headline):
     """Directional derivative of the loss along a fixed direction vs central differences.
     (The reference's analytic dK ignores the +1e-7 and the clip in cos(delta), utils.py:984 vs
