@@ -23,7 +23,7 @@ python bench.py --config thetagrid --steps 1 --warmup 0 2>/dev/null >> $out/${ta
 python bench.py --config thetagrid --dtype f32 --steps 1 --warmup 0 2>/dev/null >> $out/${tag}_configs.jsonl
 python bench.py --config thetagrid --dtype f64 --grid-points 128 --steps 1 --warmup 0 2>/dev/null >> $out/${tag}_configs.jsonl
 : > $out/${tag}_size_sweep.jsonl
-for n in 1024 2048 4096 6144 8192 12288 16384; do python bench.py --n $n --steps 6 --warmup 2 --no-cpu-baseline 2>/dev/null >> $out/${tag}_size_sweep.jsonl; done
+for n in 1024 2048 4096 6144 8192 12288 16384 32768; do python bench.py --n $n --steps 6 --warmup 2 --no-cpu-baseline 2>/dev/null >> $out/${tag}_size_sweep.jsonl; done
 : > $out/${tag}_whole_fits.log
 python examples/one_cell_fit.py --n 512 --d 64 >> $out/${tag}_whole_fits.log 2>&1
 python examples/one_cell_fit.py --n 2048 --d 256 >> $out/${tag}_whole_fits.log 2>&1
