@@ -38,6 +38,10 @@ _SIGS = {
     "gpfit_fit_eval_f32": (i32, [vp, vp, pd, pd, pd, i32, i32, vp, i64, i64, vp, vp, vp, i64, f64, f64, i32, pd,
                                  vp, vp, vp]),
     "gpfit_fit_eval_finish": (i32, [vp, pd]),
+    "gpfit_fit_eval_batch": (i32, [vp, i32, vp, pd, pd, pd, i32, i32, vp, i64, i64, vp, vp, vp, i64, pd, pd, i32, pd,
+                                   ctypes.POINTER(i32)]),
+    "gpfit_fit_eval_batch_f32": (i32, [vp, i32, vp, pd, pd, pd, i32, i32, vp, i64, i64, vp, vp, vp, i64, pd, pd, i32, pd,
+                                       ctypes.POINTER(i32)]),
     "gpfit_fit_eval_projected": (i32, [vp, vp, pd, pd, pd, i32, i32, vp, i64, i64, vp, vp, i64, i64, vp, vp, i64, f64, f64, pd]),
     "gpfit_fit_eval_sparse": (i32, [vp, vp, pd, pd, pd, i32, i32, vp, i64, i64, vp, i64, i64, vp, vp, i64, i64, vp, vp, i64,
                                     f64, f64, pd]),

@@ -187,11 +187,16 @@ __device__ __forceinline__ void static_for_inv(R (&yh)[16], R m) {
 // wave-uniform run-time conditions, and the one register operand that would need a run-time index
 // -- X[kb, j] as the B operand of the Y updates -- is copied to a fixed tile (xrow) when it is
 // produced: the slots of a column are walked in row order, so its row-kb slot comes first.
+// One workgroup per block of the batch (LeafBatchT, kernels.h): blocks of several factorisations that
+// have reached a leaf together (the K~ and V chains of a unit, the chains of several units) share the launch.
 template <typename R>
-__global__ __launch_bounds__(RL_THREADS, 2) void chol_leaf_reg_kernel(const R* __restrict__ A, int64_t lda,
-                                                                      R* __restrict__ L, int64_t ldl,
-                                                                      R* __restrict__ Linv, int64_t ldi,
-                                                                      int* __restrict__ info, int info_base) {
+__global__ __launch_bounds__(RL_THREADS, 2) void chol_leaf_reg_kernel(LeafBatchT<R> bt) {
+  const R* __restrict__ A = bt.A[blockIdx.x];
+  R* __restrict__ L = bt.L[blockIdx.x];
+  R* __restrict__ Linv = bt.Li[blockIdx.x];
+  int* __restrict__ info = bt.info[blockIdx.x];
+  const int64_t lda = bt.lda, ldl = bt.ldl, ldi = bt.ldi;
+  const int info_base = bt.info_base;
   using Acc = typename Real<R>::acc_t;
   using V = typename Real<R>::vec_t;
   constexpr int EPC = Real<R>::EPC;
@@ -371,14 +376,27 @@ __global__ __launch_bounds__(RL_THREADS, 2) void chol_leaf_reg_kernel(const R* _
 }
 
 template <typename R>
-int launch_chol_leaf_reg(const R* A, int64_t lda, R* L, int64_t ldl, R* Linv, int64_t ldi, int* info, int info_base,
-                         hipStream_t s) {
-  hipLaunchKernelGGL(chol_leaf_reg_kernel<R>, dim3(1), dim3(RL_THREADS), 0, s, A, lda, L, ldl, Linv, ldi, info,
-                     info_base);
+int launch_chol_leaf_batch(const LeafBatchT<R>& bt, hipStream_t s) {
+  if (bt.n <= 0 || bt.n > GEMM_MAXB) {
+    set_error("launch_chol_leaf_batch: 1 .. GEMM_MAXB blocks per launch");
+    return -3;
+  }
+  hipLaunchKernelGGL(chol_leaf_reg_kernel<R>, dim3(bt.n), dim3(RL_THREADS), 0, s, bt);
   GP_HIP(hipGetLastError());
   return 0;
 }
 
+template <typename R>
+int launch_chol_leaf_reg(const R* A, int64_t lda, R* L, int64_t ldl, R* Linv, int64_t ldi, int* info, int info_base,
+                         hipStream_t s) {
+  LeafBatchT<R> bt{};
+  bt.n = 1; bt.A[0] = A; bt.L[0] = L; bt.Li[0] = Linv; bt.info[0] = info;
+  bt.lda = lda; bt.ldl = ldl; bt.ldi = ldi; bt.info_base = info_base;
+  return launch_chol_leaf_batch(bt, s);
+}
+
+template int launch_chol_leaf_batch<double>(const LeafBatchT<double>&, hipStream_t);
+template int launch_chol_leaf_batch<float>(const LeafBatchT<float>&, hipStream_t);
 template int launch_chol_leaf_reg<double>(const double*, int64_t, double*, int64_t, double*, int64_t, int*, int,
                                           hipStream_t);
 template int launch_chol_leaf_reg<float>(const float*, int64_t, float*, int64_t, float*, int64_t, int*, int, hipStream_t);

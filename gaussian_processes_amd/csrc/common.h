@@ -40,6 +40,8 @@ inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
 //                  simply never read)
 // K must be a multiple of the K step (16 for fp64, 32 for fp32); M, N arbitrary (edges are
 // predicated); lda/ldb multiples of 16 bytes.
+constexpr int GEMM_MAXB = 32;  // problems of one pointer-batched launch (GemmArgsT::nptr)
+
 template <typename R>
 struct GemmArgsT {
   const R* A;
@@ -76,6 +78,18 @@ struct GemmArgsT {
   int epi;
   R* aux;
   double* sumsq;
+  // Pointer batch: nptr > 0 independent problems of the same shape, problem b (= blockIdx.y) on Ap[b], Bp[b],
+  // Cp[b] instead of A, B, C and the strides.  This is how the latency-bound levels of several Cholesky
+  // recursions (the K~ and V chains of one unit, the chains of several units in flight) and the sibling blocks of
+  // the two-sided product share their launches: the matrices live in separately allocated workspaces, so there is
+  // no common stride.  Data-parallel launches only (no stream-K, no schedule table); fused epilogues take their
+  // per-problem operands from auxp / sumsqp.
+  int nptr;
+  const R* Ap[GEMM_MAXB];
+  const R* Bp[GEMM_MAXB];
+  R* Cp[GEMM_MAXB];
+  R* auxp[GEMM_MAXB];        // epi 4: problem b's aux
+  double* sumsqp[GEMM_MAXB]; // epi 2: problem b's tile-norm table
 };
 using GemmArgs = GemmArgsT<double>;
 

@@ -125,4 +125,26 @@ using CholBufs = CholBufsT<double>;
 template <typename R>
 int potrf_rec(const CholBufsT<R>& B, int r0, int n, int need_inv, hipStream_t s);
 
+// Several chains of the same size factored in lock step (fit.hip:potrf_lockstep): chain b factors A[b] (lower
+// triangle, destroyed) into L[b] with the inverse blocks in Li[b], scratch Tmp[b], LAPACK info in info[b].
+template <typename R>
+struct CholBatchT {
+  int nb = 0;
+  R* A[GEMM_MAXB];
+  R* L[GEMM_MAXB];
+  R* Li[GEMM_MAXB];
+  R* Tmp[GEMM_MAXB];
+  int* info[GEMM_MAXB];
+  int64_t ld = 0;
+  int ws = 0;
+  void* sk_ws = nullptr;     // stream-K workspace of the launches issued chain by chain (one stream: shared)
+  gpfit_ctx* ctx = nullptr;  // look-ahead resources (side stream `chain` of this context), or nullptr
+  int chain = 0;
+  int side_min = 0;
+};
+// need: bit b = chain b needs the full inverse of its block (need_inv of potrf_rec); the diagonal sub-block
+// inverses every chain's solves need are always formed.
+template <typename R>
+int potrf_lockstep(const CholBatchT<R>& B, int r0, int n, uint32_t need, hipStream_t s);
+
 }  // namespace gpfit

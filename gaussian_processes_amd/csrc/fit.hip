@@ -106,7 +106,7 @@ double gemm_flops(const GemmArgsT<R>& g) {
       if (g.b_tri == 2) ke = std::min(ke, tj * T + T);
       if (ke > kb) steps += (ke - kb);
     }
-  return 2.0 * T * T * steps * (g.batch > 0 ? g.batch : 1);
+  return 2.0 * T * T * steps * (g.nptr > 0 ? g.nptr : (g.batch > 0 ? g.batch : 1));
 }
 
 // ------------------------------------------------------------------ GEMM convenience
@@ -126,8 +126,20 @@ static GemmArgsT<R> gemm_args(int a_kmajor, int b_kmajor, int M, int N, int K, d
   return g;
 }
 
+// tuning aid: GPFIT_GEMM_LOG=k lists every GEMM launch of the k-th evaluation of the process on stderr (shape,
+// structure flags, problems in the batch, block tile, executed flops), in launch order -- to be paired with a
+// kernel trace of the same run (scripts/trace_gemm_rates.py)
+static int g_eval_count = 0;
+static int gemm_log_eval() {
+  static const int v = getenv("GPFIT_GEMM_LOG") ? atoi(getenv("GPFIT_GEMM_LOG")) : -1;
+  return v;
+}
+
 template <typename R>
 static int run_gemm(hipStream_t s, const GemmArgsT<R>& g, bool plain = false) {
+  if (gemm_log_eval() >= 0 && g_eval_count == gemm_log_eval())
+    fprintf(stderr, "[gpfit gemm] M %d N %d K %d atri %d btri %d lower %d nb %d tile %d ak %d bk %d epi %d flops %.6e\n", g.M, g.N, g.K,
+            g.a_tri, g.b_tri, g.out_lower, g.nptr > 0 ? g.nptr : 1, gemm_pick_tile(g), g.a_kmajor, g.b_kmajor, g.epi, gemm_flops(g));
   // profile kind 0: the 128-tile kernel family (the dominant kernel), 3: the small-tile instances
   ProfScope ps(s, g_prof ? gemm_flops(g) : 0.0, (g_prof && gemm_pick_tile(g) != TILE) ? 3 : 0);
   return (plain || g.half_occ) ? launch_gemm_plain(g, s) : launch_gemm(g, s);  // plain: data-parallel, never stream-K
@@ -211,6 +223,144 @@ int potrf_rec(const CholBufsT<R>& B, int r0, int n, int need_inv, hipStream_t s)
 template int potrf_rec<double>(const CholBufsT<double>&, int, int, int, hipStream_t);
 template int potrf_rec<float>(const CholBufsT<float>&, int, int, int, hipStream_t);
 
+// ------------------------------------------------------------------ lock-step recursion over several chains
+// The same recursion for nb matrices of the same size at once (CholBatchT, context.h): the K~ and V chains of one
+// unit, or the chains of several independent units.  Every level whose launches cannot fill the chip -- the
+// leaves and the products of the small blocks, i.e. the latency-bound bottom of the recursion -- is ONE launch
+// for all chains (a pointer batch, GemmArgsT::nptr / LeafBatchT): the number of kernel boundaries on the critical
+// path no longer grows with the number of chains and every small launch has nb times the workgroups.  Products
+// that are 128-tile launches for a single chain are issued chain by chain through the ordinary launcher, with
+// its stream-K / XCD-aware schedules.  Results are bit-identical to potrf_rec: a chain's launches are the same
+// products in the same order; the batched ones are data-parallel launches exactly where potrf_rec's are (stream-K
+// only ever applies to 128-tile launches of a single problem, which take the same path here), and every
+// data-parallel instance sums k in ascending order per element whatever block tile the launcher picks.
+// need[b]: chain b needs the inverse of its block at this node (as need_inv of potrf_rec).
+// cnt problems of one shape, problem i on (Ap[i], Bp[i], Cp[i]): one pointer-batched launch, unless the product
+// is a 128-tile launch already for a single problem -- then problem by problem through the ordinary launcher.
+template <typename R>
+static int gemm_list(hipStream_t s, int cnt, const R* const* Ap, const R* const* Bp, R* const* Cp, int a_kmajor,
+                     int b_kmajor, int M, int N, int K, double alpha, int64_t lda, int64_t ldb, double beta, int64_t ldc,
+                     int out_lower, int a_tri, int b_tri, int reverse = 0, int ws_id = 0, void* sk_ws = nullptr,
+                     int epi = 0, R* const* auxp = nullptr, double* const* sumsqp = nullptr, bool* epi_done = nullptr) {
+  if (epi_done) *epi_done = false;
+  if (cnt <= 0) return 0;
+  if (cnt > GEMM_MAXB) {
+    set_error("gemm_list: more problems than a pointer batch holds");
+    return -3;
+  }
+  GemmArgsT<R> g = gemm_args<R>(a_kmajor, b_kmajor, M, N, K, alpha, Ap[0], lda, Bp[0], ldb, beta, Cp[0], ldc, out_lower,
+                                a_tri, b_tri, reverse, ws_id, sk_ws);
+  static const bool no_batch = getenv("GPFIT_NO_BATCH") != nullptr;   // tuning knob: every product on its own
+  // epi: fused epilogue wanted (common.h); *epi_done says whether the launches carried it -- all of them or none
+  // (the caller runs the separate passes otherwise)
+  if (cnt == 1 || gemm_pick_tile(g) == TILE || no_batch) {
+    bool fused = epi != 0;
+    for (int i = 0; i < cnt && fused; ++i) {
+      g.A = Ap[i]; g.B = Bp[i]; g.C = Cp[i];
+      g.epi = epi; g.aux = auxp ? auxp[i] : nullptr; g.sumsq = sumsqp ? sumsqp[i] : nullptr;
+      fused = gemm_epilogue_ok(g);
+    }
+    for (int i = 0; i < cnt; ++i) {
+      g.A = Ap[i]; g.B = Bp[i]; g.C = Cp[i];
+      g.epi = fused ? epi : 0; g.aux = (fused && auxp) ? auxp[i] : nullptr; g.sumsq = (fused && sumsqp) ? sumsqp[i] : nullptr;
+      GP_TRY(run_gemm(s, g));
+    }
+    if (epi_done) *epi_done = fused;
+    return 0;
+  }
+  g.nptr = cnt;
+  g.batch = cnt;
+  for (int i = 0; i < cnt; ++i) {
+    g.Ap[i] = Ap[i]; g.Bp[i] = Bp[i]; g.Cp[i] = Cp[i];
+    g.auxp[i] = auxp ? auxp[i] : nullptr; g.sumsqp[i] = sumsqp ? sumsqp[i] : nullptr;
+  }
+  g.epi = epi;
+  if (epi && !gemm_epilogue_ok(g)) g.epi = 0;
+  if (epi_done) *epi_done = g.epi != 0;
+  return run_gemm(s, g);
+}
+
+template <typename R>
+static int bgemm(const CholBatchT<R>& B, hipStream_t s, uint32_t mask, int a_kmajor, int b_kmajor, int M, int N, int K,
+                 double alpha, R* const* Ab, int64_t offA, R* const* Bb, int64_t offB, double beta, R* const* Cb,
+                 int64_t offC, int out_lower, int a_tri, int b_tri, int reverse, int ws_id, void* sk_ws) {
+  const R* Ap[GEMM_MAXB];
+  const R* Bp[GEMM_MAXB];
+  R* Cp[GEMM_MAXB];
+  int cnt = 0;
+  for (int b = 0; b < B.nb; ++b)
+    if (mask & (1u << b)) {
+      Ap[cnt] = Ab[b] + offA; Bp[cnt] = Bb[b] + offB; Cp[cnt] = Cb[b] + offC;
+      ++cnt;
+    }
+  return gemm_list<R>(s, cnt, Ap, Bp, Cp, a_kmajor, b_kmajor, M, N, K, alpha, B.ld, B.ld, beta, B.ld, out_lower, a_tri,
+                      b_tri, reverse, ws_id, sk_ws);
+}
+
+template <typename R>
+int potrf_lockstep(const CholBatchT<R>& B, int r0, int n, uint32_t need, hipStream_t s) {
+  const int64_t ld = B.ld;
+  const uint32_t all = (B.nb >= 32) ? 0xffffffffu : ((1u << B.nb) - 1u);
+  auto off = [&](int r, int c) { return (int64_t)r * ld + c; };
+  if (n == TILE) {
+    ProfScope ps(s, 0.0, 1);
+    LeafBatchT<R> bt{};
+    bt.n = B.nb;
+    for (int b = 0; b < B.nb; ++b) {
+      bt.A[b] = B.A[b] + off(r0, r0); bt.L[b] = B.L[b] + off(r0, r0); bt.Li[b] = B.Li[b] + off(r0, r0);
+      bt.info[b] = B.info[b];
+    }
+    bt.lda = bt.ldl = bt.ldi = ld;
+    bt.info_base = r0;
+    return launch_chol_leaf_batch(bt, s);
+  }
+  const int k = n / TILE;
+  const int n1 = ((k + 1) / 2) * TILE, n2 = n - n1;
+  const int r1 = r0 + n1;
+  GP_TRY(potrf_lockstep<R>(B, r0, n1, all, s));
+  // L21 = A21 * L11^-T
+  GP_TRY(bgemm<R>(B, s, all, 0, 0, n2, n1, n1, 1.0, B.A, off(r1, r0), B.Li, off(r0, r0), 0.0, B.L, off(r1, r0), 0, 0, 2,
+                  walks()[0], B.ws, B.sk_ws));
+  // look-ahead of the inverse merge's first product on the side stream (as potrf_rec)
+  hipEvent_t joined = nullptr;
+  if (need && B.ctx && B.side_min > 0 && n >= B.side_min && B.ctx->side[B.chain]) {
+    gpfit_ctx* c = B.ctx;
+    auto next_event = [&]() {
+      auto& pool = c->side_ev[B.chain];
+      int& nx = c->side_ev_next[B.chain];
+      if (nx == (int)pool.size()) {
+        hipEvent_t e = nullptr;
+        (void)hipEventCreateWithFlags(&e, hipEventDisableTiming);
+        pool.push_back(e);
+      }
+      return pool[nx++];
+    };
+    hipStream_t side = c->side[B.chain];
+    hipEvent_t fork = next_event();
+    joined = next_event();
+    GP_HIP(hipEventRecord(fork, s));
+    GP_HIP(hipStreamWaitEvent(side, fork, 0));
+    GP_TRY(bgemm<R>(B, side, need, 0, 1, n2, n1, n1, 1.0, B.L, off(r1, r0), B.Li, off(r0, r0), 0.0, B.Tmp, off(r1, r0), 0, 0, 1,
+                    walks()[1], 2 + B.chain, c->sk_ws[2 + B.chain]));
+    GP_HIP(hipEventRecord(joined, side));
+  }
+  // A22 -= L21 L21^T
+  GP_TRY(bgemm<R>(B, s, all, 0, 0, n2, n2, n1, -1.0, B.L, off(r1, r0), B.L, off(r1, r0), 1.0, B.A, off(r1, r1), 1, 0, 0, 0,
+                  B.ws, B.sk_ws));
+  GP_TRY(potrf_lockstep<R>(B, r1, n2, need, s));
+  if (need) {
+    if (joined) GP_HIP(hipStreamWaitEvent(s, joined, 0));
+    else GP_TRY(bgemm<R>(B, s, need, 0, 1, n2, n1, n1, 1.0, B.L, off(r1, r0), B.Li, off(r0, r0), 0.0, B.Tmp, off(r1, r0), 0, 0,
+                         1, walks()[1], B.ws, B.sk_ws));
+    GP_TRY(bgemm<R>(B, s, need, 0, 1, n2, n1, n2, -1.0, B.Li, off(r1, r1), B.Tmp, off(r1, r0), 0.0, B.Li, off(r1, r0), 0, 1, 0,
+                    walks()[2], B.ws, B.sk_ws));
+  }
+  return 0;
+}
+
+template int potrf_lockstep<double>(const CholBatchT<double>&, int, int, uint32_t, hipStream_t);
+template int potrf_lockstep<float>(const CholBatchT<float>&, int, int, uint32_t, hipStream_t);
+
 // ------------------------------------------------------------------ two-sided triangular product
 // Wout (lower) = 1/2 Li^T Q Li on the n x n diagonal block at r0, Q symmetric (stored in full),
 // Li lower triangular.  The direct route R = Q Li, W = Li^T R costs 4/3 n^3; splitting once,
@@ -221,48 +371,123 @@ template int potrf_rec<float>(const CholBufsT<float>&, int, int, int, hipStream_
 template <typename R>
 struct TwoSidedBufs {
   const R* Q; const R* Li; R* W; R* Z; R* H; int64_t ld; int min_split;
+  // optional: a side stream with two events; the top split then runs its two half-size diagonal products there,
+  // beside the three large off-diagonal products on the main stream (they depend on nothing of their level)
+  hipStream_t side = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  void* side_sk_ws = nullptr;   // stream-K workspace of the launches issued on `side`
+  void* sk_ws = nullptr;        // stream-K workspace of this block's own launches (nullptr: the main stream's)
 };
+// cnt diagonal blocks of size n (block i of problem b[i] at offset r0[i]) in lock step: the two half-size
+// two-sided products a split leaves behind (W11's A^T Q11 A and W22) depend on nothing else of their level, so
+// they -- and the sub-blocks of several units -- share their launches (gemm_list above): two 2048-sized problems
+// are one 128-tile launch of 512 workgroups instead of two 64-tile launches.  Same products, same order per
+// block: bit-identical to the block-by-block recursion.
 template <typename R>
-static int two_sided(const TwoSidedBufs<R>& b, int r0, int n, hipStream_t s) {
-  const int64_t ld = b.ld;
+static int two_sided_list(int cnt, const TwoSidedBufs<R>* b, const int* r0, int n, hipStream_t s) {
+  if (cnt <= 0) return 0;
+  const int64_t ld = b[0].ld;
   auto at = [&](const R* base, int r, int c) { return const_cast<R*>(base) + (int64_t)r * ld + c; };
+  const R* Ap[GEMM_MAXB];
+  const R* Bp[GEMM_MAXB];
+  R* Cp[GEMM_MAXB];
   const int k = n / TILE;
-  if (n < b.min_split || k < 2) {
-    GP_TRY(gemm<R>(s, 1, 1, n, n, n, 1.0, at(b.Q, r0, r0), ld, at(b.Li, r0, r0), ld, 0.0, at(b.Z, r0, r0), ld, 0, 0, 1, walks()[5]));
+  if (n < b[0].min_split || k < 2) {
     static const int wbase_walk = getenv("GPFIT_WBASE_WALK") ? atoi(getenv("GPFIT_WBASE_WALK")) : 0;
-    GP_TRY(gemm<R>(s, 1, 1, n, n, n, 0.5, at(b.Li, r0, r0), ld, at(b.Z, r0, r0), ld, 0.0, at(b.W, r0, r0), ld, 1, 2, 0, wbase_walk));
+    for (int i = 0; i < cnt; ++i) { Ap[i] = at(b[i].Q, r0[i], r0[i]); Bp[i] = at(b[i].Li, r0[i], r0[i]); Cp[i] = at(b[i].Z, r0[i], r0[i]); }
+    GP_TRY(gemm_list<R>(s, cnt, Ap, Bp, Cp, 1, 1, n, n, n, 1.0, ld, ld, 0.0, ld, 0, 0, 1, walks()[5], 0, b[0].sk_ws));
+    for (int i = 0; i < cnt; ++i) { Ap[i] = at(b[i].Li, r0[i], r0[i]); Bp[i] = at(b[i].Z, r0[i], r0[i]); Cp[i] = at(b[i].W, r0[i], r0[i]); }
+    GP_TRY(gemm_list<R>(s, cnt, Ap, Bp, Cp, 1, 1, n, n, n, 0.5, ld, ld, 0.0, ld, 1, 2, 0, wbase_walk, 0, b[0].sk_ws));
     return 0;
   }
-  const int n1 = ((k + 1) / 2) * TILE, n2 = n - n1, r1 = r0 + n1;
-  R* Z21 = at(b.Z, r1, r0);
-  R* H21 = at(b.H, r1, r0);
+  const int n1 = ((k + 1) / 2) * TILE, n2 = n - n1;
+  auto diagonal_blocks = [&](hipStream_t st) -> int {
+    // 1/2 A^T Q11 A (into W11) and W22 = 1/2 C^T Q22 C, all of them in lock step when the halves are equal
+    TwoSidedBufs<R> bb[GEMM_MAXB];
+    int rr[GEMM_MAXB];
+    if (n1 == n2 && 2 * cnt <= GEMM_MAXB) {
+      for (int i = 0; i < cnt; ++i) {
+        bb[2 * i] = b[i]; rr[2 * i] = r0[i];
+        bb[2 * i + 1] = b[i]; rr[2 * i + 1] = r0[i] + n1;
+        bb[2 * i].side = bb[2 * i + 1].side = nullptr;
+        if (st != s) bb[2 * i].sk_ws = bb[2 * i + 1].sk_ws = b[i].side_sk_ws;
+      }
+      return two_sided_list<R>(2 * cnt, bb, rr, n1, st);
+    }
+    for (int i = 0; i < cnt; ++i) { bb[i] = b[i]; bb[i].side = nullptr; rr[i] = r0[i] + n1; if (st != s) bb[i].sk_ws = b[i].side_sk_ws; }
+    GP_TRY(two_sided_list<R>(cnt, bb, r0, n1, st));
+    return two_sided_list<R>(cnt, bb, rr, n2, st);
+  };
+  const bool forked = cnt == 1 && b[0].side != nullptr;
+  if (forked) {
+    GP_HIP(hipEventRecord(b[0].ev_fork, s));
+    GP_HIP(hipStreamWaitEvent(b[0].side, b[0].ev_fork, 0));
+    GP_TRY(diagonal_blocks(b[0].side));
+    GP_HIP(hipEventRecord(b[0].ev_join, b[0].side));
+  }
   // Z21 = 1/2 Q22 B
-  GP_TRY(gemm<R>(s, 1, 1, n2, n1, n2, 0.5, at(b.Q, r1, r1), ld, at(b.Li, r1, r0), ld, 0.0, Z21, ld, 0, 0, 0));
+  for (int i = 0; i < cnt; ++i) {
+    const int r1 = r0[i] + n1;
+    Ap[i] = at(b[i].Q, r1, r1); Bp[i] = at(b[i].Li, r1, r0[i]); Cp[i] = at(b[i].Z, r1, r0[i]);
+  }
+  GP_TRY(gemm_list<R>(s, cnt, Ap, Bp, Cp, 1, 1, n2, n1, n2, 0.5, ld, ld, 0.0, ld, 0, 0, 0, 0, 0, b[0].sk_ws));
   // H = Q21 A + Z21 ;  Z21 = H + 1/2 Q22 B  (one launch with the dual-update epilogue: H = acc + Z21, Z21 += H;
-  // otherwise a copy, the product with beta = 1 and an axpby pass -- the same arithmetic)
+  // where the launch cannot carry it, a copy, the product with beta = 1 and an axpby pass -- the same arithmetic)
   {
-    GemmArgsT<R> g = gemm_args<R>(0, 1, n2, n1, n1, 1.0, at(b.Q, r1, r0), ld, at(b.Li, r0, r0), ld, 0.0, H21, ld, 0, 0, 1, walks()[6]);
-    g.epi = 4; g.aux = Z21;
-    if ((fused_epilogues() & 4) && gemm_epilogue_ok(g)) {
-      GP_TRY(run_gemm(s, g));
+    R* Zp[GEMM_MAXB];
+    for (int i = 0; i < cnt; ++i) {
+      const int r1 = r0[i] + n1;
+      Ap[i] = at(b[i].Q, r1, r0[i]); Bp[i] = at(b[i].Li, r0[i], r0[i]); Cp[i] = at(b[i].H, r1, r0[i]); Zp[i] = at(b[i].Z, r1, r0[i]);
+    }
+    // would the fused launch be possible?  (asked first: the unfused route must copy Z21 into H beforehand)
+    bool fused = false;
+    if (fused_epilogues() & 4) {
+      GemmArgsT<R> g = gemm_args<R>(0, 1, n2, n1, n1, 1.0, Ap[0], ld, Bp[0], ld, 0.0, Cp[0], ld, 0, 0, 1, walks()[6], 0, b[0].sk_ws);
+      g.epi = 4; g.aux = Zp[0];
+      static const bool no_batch = getenv("GPFIT_NO_BATCH") != nullptr;
+      if (cnt > 1 && gemm_pick_tile(g) != TILE && !no_batch) { g.nptr = cnt; g.batch = cnt; }
+      fused = gemm_epilogue_ok(g);
+    }
+    if (fused) {
+      bool done = false;
+      GP_TRY(gemm_list<R>(s, cnt, Ap, Bp, Cp, 0, 1, n2, n1, n1, 1.0, ld, ld, 0.0, ld, 0, 0, 1, walks()[6], 0, b[0].sk_ws, 4, Zp, nullptr,
+                          &done));
+      if (!done) {
+        set_error("two_sided: the dual-update epilogue was announced but not carried");
+        return -100;
+      }
     } else {
-      GP_HIP(hipMemcpy2DAsync(H21, (size_t)ld * sizeof(R), Z21, (size_t)ld * sizeof(R), (size_t)n1 * sizeof(R), (size_t)n2,
-                              hipMemcpyDeviceToDevice, s));
-      g.epi = 0; g.aux = nullptr; g.beta = 1.0;
-      GP_TRY(run_gemm(s, g));
-      GP_TRY(launch_axpby_block<R>(Z21, ld, H21, ld, n2, n1, 1.0, 1.0, s));
+      for (int i = 0; i < cnt; ++i)
+        GP_HIP(hipMemcpy2DAsync(Cp[i], (size_t)ld * sizeof(R), Zp[i], (size_t)ld * sizeof(R), (size_t)n1 * sizeof(R), (size_t)n2,
+                                hipMemcpyDeviceToDevice, s));
+      GP_TRY(gemm_list<R>(s, cnt, Ap, Bp, Cp, 0, 1, n2, n1, n1, 1.0, ld, ld, 1.0, ld, 0, 0, 1, walks()[6], 0, b[0].sk_ws));
+      for (int i = 0; i < cnt; ++i) GP_TRY(launch_axpby_block<R>(Zp[i], ld, Cp[i], ld, n2, n1, 1.0, 1.0, s));
     }
   }
   // W21 = 1/2 C^T Z21
   static const int w21_walk = getenv("GPFIT_W21_WALK") ? atoi(getenv("GPFIT_W21_WALK")) : 0;
-  GP_TRY(gemm<R>(s, 1, 1, n2, n1, n2, 0.5, at(b.Li, r1, r1), ld, Z21, ld, 0.0, at(b.W, r1, r0), ld, 0, 2, 0, w21_walk));
-  // W11 = 1/2 A^T Q11 A + 1/2 (B^T H + H^T B)   (lower tiles)
-  GP_TRY(two_sided<R>(b, r0, n1, s));
-  GP_TRY(gemm<R>(s, 1, 1, n1, n1, n2, 0.5, at(b.Li, r1, r0), ld, H21, ld, 1.0, at(b.W, r0, r0), ld, 1, 0, 0));
-  GP_TRY(gemm<R>(s, 1, 1, n1, n1, n2, 0.5, H21, ld, at(b.Li, r1, r0), ld, 1.0, at(b.W, r0, r0), ld, 1, 0, 0));
-  // W22 = 1/2 C^T Q22 C
-  GP_TRY(two_sided<R>(b, r1, n2, s));
+  for (int i = 0; i < cnt; ++i) {
+    const int r1 = r0[i] + n1;
+    Ap[i] = at(b[i].Li, r1, r1); Bp[i] = at(b[i].Z, r1, r0[i]); Cp[i] = at(b[i].W, r1, r0[i]);
+  }
+  GP_TRY(gemm_list<R>(s, cnt, Ap, Bp, Cp, 1, 1, n2, n1, n2, 0.5, ld, ld, 0.0, ld, 0, 2, 0, w21_walk, 0, b[0].sk_ws));
+  if (forked) GP_HIP(hipStreamWaitEvent(s, b[0].ev_join, 0));
+  else GP_TRY(diagonal_blocks(s));
+  // W11 += 1/2 (B^T H + H^T B)   (lower tiles)
+  for (int i = 0; i < cnt; ++i) {
+    const int r1 = r0[i] + n1;
+    Ap[i] = at(b[i].Li, r1, r0[i]); Bp[i] = at(b[i].H, r1, r0[i]); Cp[i] = at(b[i].W, r0[i], r0[i]);
+  }
+  GP_TRY(gemm_list<R>(s, cnt, Ap, Bp, Cp, 1, 1, n1, n1, n2, 0.5, ld, ld, 1.0, ld, 1, 0, 0, 0, 0, b[0].sk_ws));
+  for (int i = 0; i < cnt; ++i) {
+    const int r1 = r0[i] + n1;
+    Ap[i] = at(b[i].H, r1, r0[i]); Bp[i] = at(b[i].Li, r1, r0[i]);
+  }
+  GP_TRY(gemm_list<R>(s, cnt, Ap, Bp, Cp, 1, 1, n1, n1, n2, 0.5, ld, ld, 1.0, ld, 1, 0, 0, 0, 0, b[0].sk_ws));
   return 0;
+}
+template <typename R>
+static int two_sided(const TwoSidedBufs<R>& b, int r0, int n, hipStream_t s) {
+  return two_sided_list<R>(1, &b, &r0, n, s);
 }
 
 // ------------------------------------------------------------------ host pieces of localker
@@ -311,6 +536,18 @@ static int check_limits(const double* theta, const double* lower, const double* 
   return 0;
 }
 
+// Side streams of the two chains (look-ahead products, the diagonal blocks of the two-sided product): off the
+// critical path, lowest priority.  Created when a synchronous evaluation first wants them -- contexts that only
+// ever serve grouped / asynchronous evaluations never do, and every stream a process creates is one more
+// claimant of the few hardware queues.
+static int ensure_side_streams(gpfit_ctx* c) {
+  if (c->side[0]) return 0;
+  int least = 0, greatest = 0;
+  GP_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+  for (int i = 0; i < 2; ++i) GP_HIP(hipStreamCreateWithPriority(&c->side[i], hipStreamNonBlocking, least));
+  return 0;
+}
+
 template <typename T>
 static int dev_alloc(gpfit_ctx* c, T** p, size_t count) {
   void* q = nullptr;
@@ -329,79 +566,122 @@ struct PostJoin {
   const R *Li, *LV, *Cos, *bv, *q, *wl, *Xm, *Cmat;           // inputs
   R *T, *W, *Z, *H, *A, *Y, *tvec, *Mpart, *Mmat;             // work matrices (np^2), Y [np][dp], Mpart / Mmat
 };
+// cnt units at once (the units of a group, gpfit_fit_eval_batch; cnt = 1: the single unit): every product goes
+// through gemm_list / two_sided_list -- one pointer-batched launch where a single unit's product cannot fill the
+// chip, unit by unit through the ordinary launcher (balanced schedules, fused epilogues) where it can -- and the
+// element-wise passes run unit by unit, all on ONE stream: a stream that waits on an event is not free on this
+// runtime (every queue with a pending barrier packet slows the dispatch of the others), so a group gets its
+// concurrency from batched launches, not from streams.
 template <typename R, typename PhaseFn>
-static int post_join(gpfit_ctx* c, const PostJoin<R>& a, const Theta& th, int n, int np, int d, int dp, int n_rows,
-                     int n_cols, int want_grad, hipStream_t s, PhaseFn&& phase) {
+static int post_join_list(int cnt, gpfit_ctx* const* cs, const PostJoin<R>* a, const Theta* th, int n, int np, const int* d,
+                          const int* dp, int n_rows, int n_cols, int want_grad, hipStream_t s, PhaseFn&& phase, bool side_ok) {
   const int64_t ld = np;
+  const R* Ap[GEMM_MAXB];
+  const R* Bp[GEMM_MAXB];
+  R* Cp[GEMM_MAXB];
+  double* Sp[GEMM_MAXB];
+  if (cnt <= 0 || cnt > GEMM_MAXB) return cnt == 0 ? 0 : -3;
   // T = L^-1 L_V (lower x lower -> lower);  tr(K~^-1 V) = ||T||_F^2
   {
-    static const int t_plain_min = getenv("GPFIT_T_PLAIN_MIN") ? atoi(getenv("GPFIT_T_PLAIN_MIN")) : (1 << 30);
-    static const int t_plain_walk = getenv("GPFIT_T_PLAIN_WALK") ? atoi(getenv("GPFIT_T_PLAIN_WALK")) : 6;
-    const bool dp = np >= t_plain_min;
-    GemmArgsT<R> g = gemm_args<R>(0, 1, np, np, np, 1.0, a.Li, ld, a.LV, ld, 0.0, a.T, ld, 1, 1, 1, dp ? t_plain_walk : walks()[3]);
-    g.epi = 2; g.sumsq = c->frob_part;
-    if ((fused_epilogues() & 2) && !dp && gemm_epilogue_ok(g)) {
-      // the tiles leave their sums of squares behind: no separate pass over T
-      GP_TRY(run_gemm(s, g));
-      GP_TRY(launch_frob_finish(c->frob_part, (np / TILE) * (np / TILE + 1) / 2, c->scal + 5, s));
-    } else {
-      g.epi = 0; g.sumsq = nullptr;
-      GP_TRY(run_gemm(s, g, dp));
-      GP_TRY(launch_frob_lower(a.T, ld, np, c->scal + 5, c->frob_part, s));
+    for (int i = 0; i < cnt; ++i) { Ap[i] = a[i].Li; Bp[i] = a[i].LV; Cp[i] = a[i].T; Sp[i] = cs[i]->frob_part; }
+    bool normed = false;
+    // the tiles leave their sums of squares behind (no separate pass over T) where the launch can carry the epilogue
+    GP_TRY(gemm_list<R>(s, cnt, Ap, Bp, Cp, 0, 1, np, np, np, 1.0, ld, ld, 0.0, ld, 1, 1, 1, walks()[3], 0, cs[0]->sk_ws[0],
+                        (fused_epilogues() & 2) ? 2 : 0, nullptr, Sp, &normed));
+    for (int i = 0; i < cnt; ++i) {
+      if (normed) GP_TRY(launch_frob_finish(cs[i]->frob_part, (np / TILE) * (np / TILE + 1) / 2, cs[i]->scal + 5, s));
+      else GP_TRY(launch_frob_lower(a[i].T, ld, np, cs[i]->scal + 5, cs[i]->frob_part, s));
     }
   }
   phase(4, s);
-
-  if (want_grad) {
-    // W = 1/2 (K~^-1 - K~^-1 V K~^-1) = 1/2 Li^T (I - T T^T) Li        (T = L^-1 L_V)
-    //   Q = I - T T^T   lower x upper, lower tiles only          N^3/3
-    //   W = 1/2 Li^T Q Li  two-sided product (two_sided above)   13/12 N^3 with one split
-    //                      (direct: R = Q Li, W = 1/2 Li^T R     4/3 N^3)
-    {
-      // T T^T: every tile of a tile column has the same k range [0, col + 128).  XCD-aware macro-tile
-      // schedule (2.97 ms at N = 8192 in the fit; the column-major heavy-first data-parallel walk 3.02,
-      // stream-K 3.2); GPFIT_Q_PLAIN_MIN restores the column-major walk above that size
-      static const int q_plain_min = getenv("GPFIT_Q_PLAIN_MIN") ? atoi(getenv("GPFIT_Q_PLAIN_MIN")) : (1 << 30);
-      const bool dp = np >= q_plain_min;
-      GemmArgsT<R> g = gemm_args<R>(0, 0, np, np, np, -1.0, a.T, ld, a.T, ld, 0.0, a.W, ld, 1, 1, 2, dp ? 3 : walks()[4]);
-      g.epi = 1;
-      const bool mirrored = (fused_epilogues() & 1) && !dp && gemm_epilogue_ok(g);
-      if (!mirrored) g.epi = 0;
-      GP_TRY(run_gemm(s, g, dp));
-      GP_TRY(launch_add_diag(a.W, ld, np, 1.0, s));
-      if (!mirrored) GP_TRY(launch_symmetrize(a.W, ld, np, s));   // otherwise the tiles stored their transposes
+  if (!want_grad) return 0;
+  // W = 1/2 (K~^-1 - K~^-1 V K~^-1) = 1/2 Li^T (I - T T^T) Li        (T = L^-1 L_V)
+  //   Q = I - T T^T   lower x upper, lower tiles only          N^3/3
+  //   W = 1/2 Li^T Q Li  two-sided product (two_sided_list)    13/12 N^3 with one split
+  //                      (direct: R = Q Li, W = 1/2 Li^T R     4/3 N^3)
+  {
+    // T T^T: every tile of a tile column has the same k range [0, col + 128).  XCD-aware macro-tile schedule for
+    // a single large unit (2.97 ms at N = 8192 in the fit; the column-major heavy-first data-parallel walk 3.02,
+    // stream-K 3.2)
+    for (int i = 0; i < cnt; ++i) { Ap[i] = a[i].T; Bp[i] = a[i].T; Cp[i] = a[i].W; }
+    bool mirrored = false;
+    GP_TRY(gemm_list<R>(s, cnt, Ap, Bp, Cp, 0, 0, np, np, np, -1.0, ld, ld, 0.0, ld, 1, 1, 2, walks()[4], 0, cs[0]->sk_ws[0],
+                        (fused_epilogues() & 1) ? 1 : 0, nullptr, nullptr, &mirrored));
+    for (int i = 0; i < cnt; ++i) {
+      GP_TRY(launch_add_diag(a[i].W, ld, np, 1.0, s));
+      if (!mirrored) GP_TRY(launch_symmetrize(a[i].W, ld, np, s));   // otherwise the tiles stored their transposes
     }
-    phase(5, s);
-    {
-      static const int ts_min = getenv("GPFIT_TS_MIN") ? atoi(getenv("GPFIT_TS_MIN")) : 4096;
-      TwoSidedBufs<R> tb{a.W, a.Li, a.T, a.Z, a.H, ld, ts_min > 0 ? ts_min : (1 << 30)};
-      GP_TRY(two_sided<R>(tb, 0, np, s));
-    }
-    phase(6, s);
-    GP_TRY(launch_adjoint(a.T, a.Cos, ld, a.bv, a.q, n, np, a.A, c->upart, c->vpart, c->sumA_part, s));
-    const int t64 = np / 64;
-    GP_TRY(launch_adjoint_reduce(c->upart, c->vpart, c->sumA_part, t64, t64 * (t64 + 1) / 2, a.q, a.wl, n, np,
-                                 a.tvec, c->rpad, c->scal + 7, s));
-    // pull the contraction with dK~ back to the d x d metric: M = X^T (Aw + diag t) X
-    GP_TRY(gemm<R>(s, 1, 1, np, dp, np, 1.0, a.A, ld, a.Xm, dp, 0.0, a.Y, dp, 0, 0, 0));
-    GP_TRY(launch_rowscale_add(a.Y, dp, a.Xm, dp, a.tvec, np, dp, s));
-    {
-      GemmArgsT<R> g{};
-      g.A = a.Xm; g.B = a.Y; g.C = a.Mpart;
-      g.lda = dp; g.ldb = dp; g.ldc = dp;
-      g.M = dp; g.N = dp; g.K = np;
-      g.alpha = 1.0; g.beta = 0.0; g.a_kmajor = 1; g.b_kmajor = 1;
-      g.batch = 1; g.split_k = c->split_k_M; g.sC = (int64_t)dp * dp;
-      {
-        ProfScope ps(s, g_prof ? gemm_flops(g) : 0.0, (g_prof && gemm_pick_tile(g) != TILE) ? 3 : 0);
-        GP_TRY(launch_gemm(g, s));
-      }
-      GP_TRY(launch_reduce_slices(a.Mpart, (int64_t)dp * dp, c->split_k_M, a.Mmat, (int64_t)dp * dp, s));
-    }
-    GP_TRY(launch_metric_contract(th, c->pix, d, n_rows, n_cols, a.Cmat, dp, a.Mmat, dp, c->scal + 10, c->upart, c->info + 3, s));
   }
-
+  phase(5, s);
+  {
+    static const int ts_min = getenv("GPFIT_TS_MIN") ? atoi(getenv("GPFIT_TS_MIN")) : 4096;
+    TwoSidedBufs<R> tb[GEMM_MAXB];
+    int r0[GEMM_MAXB];
+    for (int i = 0; i < cnt; ++i) {
+      tb[i] = TwoSidedBufs<R>{a[i].W, a[i].Li, a[i].T, a[i].Z, a[i].H, ld, ts_min > 0 ? ts_min : (1 << 30)};
+      tb[i].sk_ws = cs[0]->sk_ws[0];
+      r0[i] = 0;
+    }
+    // tuning knob: the half-size diagonal products of the top split on the chain-0 side stream (a single unit
+    // evaluated synchronously only, as the look-ahead of the factorisation)
+    static const int ts_side = getenv("GPFIT_TS_SIDE") ? atoi(getenv("GPFIT_TS_SIDE")) : 0;
+    gpfit_ctx* c = cs[0];
+    if (cnt == 1 && ts_side && side_ok && c->side[0]) {
+      auto next_event = [&]() {
+        auto& pool = c->side_ev[0];
+        int& nx = c->side_ev_next[0];
+        if (nx == (int)pool.size()) {
+          hipEvent_t e = nullptr;
+          (void)hipEventCreateWithFlags(&e, hipEventDisableTiming);
+          pool.push_back(e);
+        }
+        return pool[nx++];
+      };
+      tb[0].side = c->side[0]; tb[0].ev_fork = next_event(); tb[0].ev_join = next_event(); tb[0].side_sk_ws = c->sk_ws[2];
+    }
+    GP_TRY(two_sided_list<R>(cnt, tb, r0, np, s));
+  }
+  phase(6, s);
+  const int t64 = np / 64;
+  for (int i = 0; i < cnt; ++i) {
+    gpfit_ctx* c = cs[i];
+    GP_TRY(launch_adjoint(a[i].T, a[i].Cos, ld, a[i].bv, a[i].q, n, np, a[i].A, c->upart, c->vpart, c->sumA_part, s));
+    GP_TRY(launch_adjoint_reduce(c->upart, c->vpart, c->sumA_part, t64, t64 * (t64 + 1) / 2, a[i].q, a[i].wl, n, np,
+                                 a[i].tvec, c->rpad, c->scal + 7, s));
+  }
+  // pull the contraction with dK~ back to the d x d metric: M = X^T (Aw + diag t) X   (units with the same
+  // masked pixel count share the launch)
+  {
+    bool same_dp = true;
+    for (int i = 1; i < cnt; ++i) same_dp = same_dp && dp[i] == dp[0];
+    for (int i = 0; i < cnt; ++i) { Ap[i] = a[i].A; Bp[i] = a[i].Xm; Cp[i] = a[i].Y; }
+    if (same_dp) GP_TRY(gemm_list<R>(s, cnt, Ap, Bp, Cp, 1, 1, np, dp[0], np, 1.0, ld, dp[0], 0.0, dp[0], 0, 0, 0, 0, 0, cs[0]->sk_ws[0]));
+    else
+      for (int i = 0; i < cnt; ++i) GP_TRY(gemm<R>(s, 1, 1, np, dp[i], np, 1.0, a[i].A, ld, a[i].Xm, dp[i], 0.0, a[i].Y, dp[i], 0, 0, 0));
+  }
+  for (int i = 0; i < cnt; ++i) {
+    gpfit_ctx* c = cs[i];
+    GP_TRY(launch_rowscale_add(a[i].Y, dp[i], a[i].Xm, dp[i], a[i].tvec, np, dp[i], s));
+    GemmArgsT<R> g{};
+    g.A = a[i].Xm; g.B = a[i].Y; g.C = a[i].Mpart;
+    g.lda = dp[i]; g.ldb = dp[i]; g.ldc = dp[i];
+    g.M = dp[i]; g.N = dp[i]; g.K = np;
+    g.alpha = 1.0; g.beta = 0.0; g.a_kmajor = 1; g.b_kmajor = 1;
+    g.batch = 1; g.split_k = c->split_k_M; g.sC = (int64_t)dp[i] * dp[i];
+    {
+      ProfScope ps(s, g_prof ? gemm_flops(g) : 0.0, (g_prof && gemm_pick_tile(g) != TILE) ? 3 : 0);
+      GP_TRY(launch_gemm(g, s));
+    }
+    GP_TRY(launch_reduce_slices(a[i].Mpart, (int64_t)dp[i] * dp[i], c->split_k_M, a[i].Mmat, (int64_t)dp[i] * dp[i], s));
+    GP_TRY(launch_metric_contract(th[i], c->pix, d[i], n_rows, n_cols, a[i].Cmat, dp[i], a[i].Mmat, dp[i], c->scal + 10, c->upart,
+                                  c->info + 3, s));
+  }
   return 0;
+}
+template <typename R, typename PhaseFn>
+static int post_join(gpfit_ctx* c, const PostJoin<R>& a, const Theta& th, int n, int np, int d, int dp, int n_rows,
+                     int n_cols, int want_grad, hipStream_t s, PhaseFn&& phase, bool side_ok) {
+  return post_join_list<R>(1, &c, &a, &th, n, np, &d, &dp, n_rows, n_cols, want_grad, s, phase, side_ok);
 }
 
 // The fused unit of work, templated on the scalar type of the device data: fp64 is the
@@ -449,6 +729,7 @@ static int fit_eval_impl(gpfit_ctx* c, void* stream, const double* theta, const 
   const int64_t ld = np;
   c->cur_n = n; c->cur_np = np; c->cur_d = d; c->cur_dp = dp;
 
+  ++g_eval_count;
   const auto t_host0 = std::chrono::steady_clock::now();
   auto phase = [&](int i, hipStream_t st) {
     if (c->profile != 2) return;
@@ -488,6 +769,7 @@ static int fit_eval_impl(gpfit_ctx* c, void* stream, const double* theta, const 
   // four in flight: 161 -> 118 cells/s with side streams)
   static const int side_min_env = getenv("GPFIT_SIDE_MIN") ? atoi(getenv("GPFIT_SIDE_MIN")) : 1024;
   const int side_min = async_call ? 0 : side_min_env;
+  if (!async_call) GP_TRY(ensure_side_streams(c));
   // tuning knob (bit mask): 1 = the V chain's own 128-tile launches at one workgroup per CU, 2 = the
   // side-stream products of both chains
   static const int half_occ = getenv("GPFIT_HALF_OCC") ? atoi(getenv("GPFIT_HALF_OCC")) : 0;
@@ -504,7 +786,19 @@ static int fit_eval_impl(gpfit_ctx* c, void* stream, const double* theta, const 
     GP_HIP(hipEventRecord(c->ev_join, sa));
     return 0;
   };
-  if (!fork_late) GP_TRY(enqueue_v_chain());
+  // Lock-step mode (default; GPFIT_LOCKSTEP=0 restores the two free-running chains): the V chain is not a
+  // stream of its own -- both matrices go through ONE recursion (potrf_lockstep) whose latency-bound levels are
+  // shared launches.  Only V's packing runs on the aux stream, beside the kernel build.
+  static const int lockstep_env = getenv("GPFIT_LOCKSTEP") ? atoi(getenv("GPFIT_LOCKSTEP")) : 1;
+  const bool lockstep = lockstep_env != 0 && !reuse_V;
+  if (lockstep) {
+    c->lv_valid = false; c->lv32_valid = false;
+    GP_HIP(hipEventRecord(c->ev_fork, s));
+    GP_HIP(hipStreamWaitEvent(sa, c->ev_fork, 0));
+    GP_TRY(launch_pack_lower(V, ldv, n, RP(c->Vbuf), ld, np, sa));
+    GP_HIP(hipEventRecord(c->ev_join, sa));
+  }
+  if (!fork_late && !lockstep) GP_TRY(enqueue_v_chain());
 
   // ---- main stream: metric, kernel matrix, moments, Cholesky of K~ with its inverse
   GP_TRY(launch_localker<R>(th, c->pix, d, dp, n_rows, n_cols, RP(c->Cmat), dp, nullptr, s));
@@ -525,12 +819,22 @@ static int fit_eval_impl(gpfit_ctx* c, void* stream, const double* theta, const 
   // tuning knob: start the V chain only when the K~ chain has factored its leading block of this size
   static const int v_after = getenv("GPFIT_V_AFTER") ? atoi(getenv("GPFIT_V_AFTER")) : 0;
   const bool v_marked = fork_late && !async_call && v_after >= TILE && v_after < np;
-  if (fork_late && !v_marked) {
+  if (lockstep) {
+    GP_HIP(hipStreamWaitEvent(s, c->ev_join, 0));   // V is packed
+    CholBatchT<R> cb;
+    cb.nb = 2;
+    cb.A[0] = RP(c->Kbuf); cb.L[0] = RP(c->Lbuf); cb.Li[0] = RP(c->Libuf); cb.Tmp[0] = RP(c->Tmp); cb.info[0] = c->info + 0;
+    cb.A[1] = RP(c->Vbuf); cb.L[1] = RP(c->LVbuf); cb.Li[1] = RP(c->LiVbuf); cb.Tmp[1] = RP(c->TmpV); cb.info[1] = c->info + 1;
+    cb.ld = ld; cb.ws = 0; cb.sk_ws = c->sk_ws[0]; cb.ctx = c; cb.chain = 0; cb.side_min = side_min;
+    GP_TRY(potrf_lockstep<R>(cb, 0, np, 1u, s));
+    GP_TRY(launch_logdet(RP(c->LVbuf), ld, n, c->scal + 40, s));
+    phase(3, s);
+  } else if (fork_late && !v_marked) {
     GP_HIP(hipEventRecord(c->ev_fork, s));
     GP_HIP(hipStreamWaitEvent(sa, c->ev_fork, 0));
     GP_TRY(enqueue_v_chain());
   }
-  {
+  if (!lockstep) {
     CholBufsT<R> bk{RP(c->Kbuf), RP(c->Lbuf), RP(c->Libuf), RP(c->Tmp), ld, c->info + 0, 0, c->sk_ws[0], c, 0, side_min, half_occ & 2};
     if (v_marked) { bk.mark_ev = c->ev_fork; bk.mark_n = v_after; }
     GP_TRY(potrf_rec<R>(bk, 0, np, true, s));
@@ -546,7 +850,7 @@ static int fit_eval_impl(gpfit_ctx* c, void* stream, const double* theta, const 
 
   phase(2, s);
   // ---- join: everything that needs both factors
-  GP_HIP(hipStreamWaitEvent(s, c->ev_join, 0));
+  if (!lockstep) GP_HIP(hipStreamWaitEvent(s, c->ev_join, 0));
   {
     PostJoin<R> pj{RP(c->Libuf), RP(c->LVbuf), RP(c->Cos), RP(c->bv), RP(c->q), RP(c->wl), RP(c->Xm), RP(c->Cmat),
                    RP(c->Tbuf), RP(c->Wbuf), RP(c->Zbuf), RP(c->Tmp), RP(c->Abuf), RP(c->Ybuf), RP(c->tvec),
@@ -570,9 +874,9 @@ static int fit_eval_impl(gpfit_ctx* c, void* stream, const double* theta, const 
       PostJoin<float> pf{F(c->Kbuf), F(c->Vbuf), F(c->TmpV), F(c->q2), F(c->dq1), F(c->dq2), F(c->Xt2), F(c->dCpad),
                          F(c->Tbuf), F(c->Wbuf), F(c->Zbuf), F(c->Tmp), F(c->Abuf), F(c->Ybuf), F(c->tvec),
                          F(c->Mpart), F(c->Mmat)};
-      GP_TRY(post_join<float>(c, pf, th, n, np, d, dp, n_rows, n_cols, want_grad, s, phase));
+      GP_TRY(post_join<float>(c, pf, th, n, np, d, dp, n_rows, n_cols, want_grad, s, phase, !async_call));
     } else {
-      GP_TRY(post_join<R>(c, pj, th, n, np, d, dp, n_rows, n_cols, want_grad, s, phase));
+      GP_TRY(post_join<R>(c, pj, th, n, np, d, dp, n_rows, n_cols, want_grad, s, phase, !async_call));
     }
   }
 
@@ -588,6 +892,208 @@ static int fit_eval_impl(gpfit_ctx* c, void* stream, const double* theta, const 
   c->pend.n = n; c->pend.np = np; c->pend.d = d; c->pend.want_grad = want_grad; c->pend.elem_bytes = (int)sizeof(R);
   if (async_call) return 0;
   return fit_eval_finish(c, out_host);
+}
+
+// Several independent units (cells, hyperparameter-grid points: SURVEY 8(e)) of the same N in one call, each on
+// its own context (its own workspace), all on the caller's stream.  The factorisations of ALL units -- 2 chains
+// per unit -- are one lock-step recursion (potrf_lockstep): its latency-bound leaves and small products are
+// shared launches, so their cost is paid once per group instead of once per unit; the products behind the
+// factorisations share their launches the same way wherever one unit's product cannot fill the chip
+// (post_join_list).  Every unit's numbers are bit-identical to gpfit_fit_eval on its own.
+// want_grad bits as gpfit_fit_eval (1 gradients, 2 reuse this context's V factor, 8 mixed precision); bit 2
+// (asynchronous) is implied: the call returns after enqueuing and the units are collected one by one with
+// gpfit_fit_eval_finish.  rc_out[u]: 0 enqueued (collect it), -2 theta outside the limits (out_host[16 u ..]
+// already holds the infinite loss / gradients, nothing to collect).
+template <typename R>
+static int fit_eval_batch_impl(gpfit_ctx* const* cs, int nu, void* stream, const double* theta6, const double* lower,
+                               const double* upper, int n_rows, int n_cols, const R* const* X, int64_t ldx, int64_t N,
+                               const R* const* r, const R* const* m, const R* const* V, int64_t ldv, const double* logA,
+                               const double* lambda0, int want_grad, double* out_host, int* rc_out) {
+  auto RP = [](double* b) { return reinterpret_cast<R*>(b); };
+  if (!cs || nu <= 0 || 2 * nu > GEMM_MAXB || !theta6 || !X || !r || !m || !V || !logA || !lambda0 || !out_host || !rc_out ||
+      N <= 0) {
+    set_error("gpfit_fit_eval_batch: bad argument (1 .. 16 units per call)");
+    return -3;
+  }
+  for (int u = 0; u < nu; ++u) {
+    if (!cs[u] || !X[u] || !r[u] || !m[u] || !V[u]) {
+      set_error("gpfit_fit_eval_batch: null context or operand");
+      return -3;
+    }
+    if (cs[u]->device != cs[0]->device) {
+      set_error("gpfit_fit_eval_batch: the contexts of one call must live on one device");
+      return -3;
+    }
+    for (int v = 0; v < u; ++v)
+      if (cs[v] == cs[u]) {
+        set_error("gpfit_fit_eval_batch: every unit needs a context of its own");
+        return -3;
+      }
+    if (cs[u]->pend.active) {
+      set_error("gpfit_fit_eval_batch: an asynchronous evaluation is pending on one of the contexts");
+      return -3;
+    }
+  }
+  DeviceGuard device_guard(cs[0]->device);
+  hipStream_t s = (hipStream_t)stream;
+  const int n = (int)N, np = (int)round_up(N, TILE);
+  const int dfull = n_rows * n_cols;
+  const int64_t ld = np;
+  const double inf = std::numeric_limits<double>::infinity();
+  const bool mixed_grad = (want_grad & 8) != 0 && sizeof(R) == 8 && (want_grad & 1);
+  const bool want_reuse = (want_grad & 2) != 0;
+  want_grad &= 1;
+  const auto t_host0 = std::chrono::steady_clock::now();
+
+  struct Unit { gpfit_ctx* c; int u, d, dp; Theta th; double A; bool reuse_V; };
+  Unit un[GEMM_MAXB];
+  int na = 0;
+  for (int u = 0; u < nu; ++u) {
+    gpfit_ctx* c = cs[u];
+    const double* theta = theta6 + 6 * u;
+    double* out = out_host + 16 * u;
+    rc_out[u] = 0;
+    if (lower && upper && check_limits(theta, lower, upper) != 0) {   // utils.py:2020-2028
+      out[0] = inf;
+      out[1] = out[2] = std::numeric_limits<double>::quiet_NaN();
+      for (int i = 0; i < 6; ++i) out[3 + i] = inf;
+      rc_out[u] = -2;
+      continue;
+    }
+    if (np > c->np_cap || dfull > c->dfull_cap) {
+      set_error("gpfit_fit_eval_batch: problem larger than a context's capacity");
+      return -3;
+    }
+    const int d = compute_mask(theta, n_rows, n_cols, nullptr, c->pix_host);
+    const int dp = (int)round_up(d, 32);
+    if (d <= 0 || dp > c->dp_cap) {
+      set_error("gpfit_fit_eval_batch: masked pixel count is zero or exceeds a context's capacity");
+      return -3;
+    }
+    Unit& q = un[na++];
+    q.c = c; q.u = u; q.d = d; q.dp = dp; q.th = make_theta(theta); q.A = std::exp(logA[u]);
+    q.reuse_V = want_reuse && c->lv_valid && c->lv_n == n && c->lv_bytes == (int)sizeof(R);
+    c->cur_n = n; c->cur_np = np; c->cur_d = d; c->cur_dp = dp;
+    c->phase_valid = false;
+    c->side_ev_next[0] = c->side_ev_next[1] = 0;
+  }
+  if (na == 0) return 0;
+  gpfit_ctx* c0 = un[0].c;
+  // tuning aid: GPFIT_BATCH_TIMES=1 prints the three phases of every group (synchronises: not for timed runs)
+  static const bool batch_times = getenv("GPFIT_BATCH_TIMES") != nullptr;
+  hipEvent_t tev[4] = {nullptr, nullptr, nullptr, nullptr};
+  if (batch_times) {
+    for (auto& e : tev) (void)hipEventCreate(&e);
+    (void)hipEventRecord(tev[0], s);
+  }
+  // Everything on the caller's stream (post_join_list: a group gets its concurrency from batched launches).
+  // ---- phase 1, unit by unit: kernel build, moments, V packed
+  for (int i = 0; i < na; ++i) {
+    Unit& q = un[i];
+    gpfit_ctx* c = q.c;
+    const int d = q.d, dp = q.dp;
+    const double s0sq = q.th.sigma0 * q.th.sigma0;
+    g_main_sk_ws = c0->sk_ws[0];
+    GP_HIP(hipMemsetAsync(c->info, 0, 4 * sizeof(int), s));
+    GP_HIP(hipMemcpyAsync(c->pix, c->pix_host, (size_t)d * sizeof(int), hipMemcpyHostToDevice, s));
+    GP_HIP(hipMemsetAsync(RP(c->mpad), 0, (size_t)np * sizeof(R), s));
+    GP_HIP(hipMemcpyAsync(RP(c->mpad), m[q.u], (size_t)n * sizeof(R), hipMemcpyDeviceToDevice, s));
+    GP_TRY(launch_localker<R>(q.th, c->pix, d, dp, n_rows, n_cols, RP(c->Cmat), dp, nullptr, s));
+    GP_TRY(launch_gather(X[q.u], ldx, n, c->pix, d, dp, np, RP(c->Xt), ld, RP(c->Xm), dp, s));
+    GP_TRY(gemm<R>(s, 1, 1, dp, np, dp, 1.0, RP(c->Cmat), dp, RP(c->Xt), ld, 0.0, RP(c->XCt), ld, 0, 0, 0));
+    GP_TRY(launch_qvec(RP(c->Xt), RP(c->XCt), ld, dp, n, np, s0sq, RP(c->Kvec), RP(c->q), s));
+    {
+      GramArgsT<R> g{};
+      g.XCt = RP(c->XCt); g.Xt = RP(c->Xt); g.q1 = RP(c->q); g.q2 = RP(c->q); g.Kout = RP(c->Kbuf); g.Cos = RP(c->Cos);
+      g.ld1 = ld; g.ld2 = ld; g.ldk = ld; g.np1 = np; g.np2 = np; g.nv1 = n; g.nv2 = n; g.Kd = dp;
+      g.s0sq = s0sq; g.lower = 1; g.pad_identity = 1;
+      GP_TRY(launch_gram(g, s));
+    }
+    GP_TRY(launch_moments(RP(c->Kvec), RP(c->q), RP(c->Cos), ld, V[q.u], ldv, m[q.u], r[q.u], n, q.A, lambda0[q.u], RP(c->lam_m),
+                          RP(c->lam_var), RP(c->fvec), RP(c->wl), c->scal, s));
+    if (!q.reuse_V) {
+      c->lv_valid = false; c->lv32_valid = false;
+      GP_TRY(launch_pack_lower(V[q.u], ldv, n, RP(c->Vbuf), ld, np, s));
+    }
+  }
+  if (batch_times) (void)hipEventRecord(tev[1], s);
+  // ---- phase 2: all factorisations in lock step
+  {
+    CholBatchT<R> cb;
+    uint32_t need = 0;
+    for (int i = 0; i < na; ++i) {
+      gpfit_ctx* c = un[i].c;
+      int b = cb.nb++;
+      cb.A[b] = RP(c->Kbuf); cb.L[b] = RP(c->Lbuf); cb.Li[b] = RP(c->Libuf); cb.Tmp[b] = RP(c->Tmp); cb.info[b] = c->info + 0;
+      need |= 1u << b;
+      if (un[i].reuse_V) continue;
+      b = cb.nb++;
+      cb.A[b] = RP(c->Vbuf); cb.L[b] = RP(c->LVbuf); cb.Li[b] = RP(c->LiVbuf); cb.Tmp[b] = RP(c->TmpV); cb.info[b] = c->info + 1;
+    }
+    cb.ld = ld; cb.ws = 0; cb.sk_ws = c0->sk_ws[0]; cb.ctx = nullptr; cb.side_min = 0;
+    GP_TRY(potrf_lockstep<R>(cb, 0, np, need, s));
+  }
+  if (batch_times) (void)hipEventRecord(tev[2], s);
+  // ---- phase 3: everything that needs the factors
+  auto no_phase = [](int, hipStream_t) {};
+  gpfit_ctx* cl[GEMM_MAXB];
+  Theta thl[GEMM_MAXB];
+  int dl[GEMM_MAXB], dpl[GEMM_MAXB];
+  PostJoin<R> pjl[GEMM_MAXB];
+  PostJoin<float> pfl[GEMM_MAXB];
+  for (int i = 0; i < na; ++i) {
+    Unit& q = un[i];
+    gpfit_ctx* c = q.c;
+    const int dp = q.dp;
+    cl[i] = c; thl[i] = q.th; dl[i] = q.d; dpl[i] = dp;
+    if (!q.reuse_V) GP_TRY(launch_logdet(RP(c->LVbuf), ld, n, c->scal + 40, s));
+    GP_TRY(launch_logdet(RP(c->Lbuf), ld, n, c->scal + 3, s));
+    GP_TRY(launch_trmv_lower(RP(c->Libuf), ld, np, RP(c->mpad), RP(c->yv), s));
+    GP_TRY(launch_dot(RP(c->yv), RP(c->yv), np, c->scal + 6, s));
+    GP_TRY(launch_trmv_lower_t(RP(c->Libuf), ld, np, RP(c->yv), RP(c->bv), c->trmv_part, s));
+    pjl[i] = PostJoin<R>{RP(c->Libuf), RP(c->LVbuf), RP(c->Cos), RP(c->bv), RP(c->q), RP(c->wl), RP(c->Xm), RP(c->Cmat),
+                         RP(c->Tbuf), RP(c->Wbuf), RP(c->Zbuf), RP(c->Tmp), RP(c->Abuf), RP(c->Ybuf), RP(c->tvec),
+                         RP(c->Mpart), RP(c->Mmat)};
+    if (mixed_grad) {
+      auto F = [](double* b) { return reinterpret_cast<float*>(b); };
+      const int64_t nn = (int64_t)np * np;
+      GP_TRY((launch_reduce_slices<double, float>(c->Libuf, nn, 1, F(c->Kbuf), nn, s)));
+      if (!(q.reuse_V && c->lv32_valid)) GP_TRY((launch_reduce_slices<double, float>(c->LVbuf, nn, 1, F(c->Vbuf), nn, s)));
+      c->lv32_valid = true;
+      GP_TRY((launch_reduce_slices<double, float>(c->Cos, nn, 1, F(c->TmpV), nn, s)));
+      GP_TRY((launch_reduce_slices<double, float>(c->bv, np, 1, F(c->q2), np, s)));
+      GP_TRY((launch_reduce_slices<double, float>(c->q, np, 1, F(c->dq1), np, s)));
+      GP_TRY((launch_reduce_slices<double, float>(c->wl, np, 1, F(c->dq2), np, s)));
+      GP_TRY((launch_reduce_slices<double, float>(c->Xm, (int64_t)np * dp, 1, F(c->Xt2), (int64_t)np * dp, s)));
+      GP_TRY((launch_reduce_slices<double, float>(c->Cmat, (int64_t)dp * dp, 1, F(c->dCpad), (int64_t)dp * dp, s)));
+      pfl[i] = PostJoin<float>{F(c->Kbuf), F(c->Vbuf), F(c->TmpV), F(c->q2), F(c->dq1), F(c->dq2), F(c->Xt2), F(c->dCpad),
+                               F(c->Tbuf), F(c->Wbuf), F(c->Zbuf), F(c->Tmp), F(c->Abuf), F(c->Ybuf), F(c->tvec),
+                               F(c->Mpart), F(c->Mmat)};
+    }
+  }
+  if (mixed_grad) GP_TRY(post_join_list<float>(na, cl, pfl, thl, n, np, dl, dpl, n_rows, n_cols, want_grad, s, no_phase, false));
+  else GP_TRY(post_join_list<R>(na, cl, pjl, thl, n, np, dl, dpl, n_rows, n_cols, want_grad, s, no_phase, false));
+  for (int i = 0; i < na; ++i) {
+    Unit& q = un[i];
+    gpfit_ctx* c = q.c;
+    GP_HIP(hipMemcpyAsync(c->scal_host, c->scal, 64 * sizeof(double), hipMemcpyDeviceToHost, s));
+    GP_HIP(hipMemcpyAsync(c->info_host, c->info, 4 * sizeof(int), hipMemcpyDeviceToHost, s));
+    c->pend.active = true; c->pend.stream = s; c->pend.A = q.A; c->pend.lambda0 = lambda0[q.u]; c->pend.sigma0 = q.th.sigma0;
+    c->pend.n = n; c->pend.np = np; c->pend.d = q.d; c->pend.want_grad = want_grad; c->pend.elem_bytes = (int)sizeof(R);
+  }
+  c0->last_enqueue_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_host0).count();
+  if (batch_times) {
+    (void)hipEventRecord(tev[3], s);
+    (void)hipEventSynchronize(tev[3]);
+    float a = 0, b = 0, d3 = 0;
+    (void)hipEventElapsedTime(&a, tev[0], tev[1]);
+    (void)hipEventElapsedTime(&b, tev[1], tev[2]);
+    (void)hipEventElapsedTime(&d3, tev[2], tev[3]);
+    fprintf(stderr, "[gpfit batch] %d units: build %.3f ms, lock-step factorisations %.3f ms, post %.3f ms (enqueue %.2f ms)\n", na, a,
+            b, d3, c0->last_enqueue_ms);
+    for (auto& e : tev) (void)hipEventDestroy(e);
+  }
+  return 0;
 }
 
 // Gradient pull-back for an externally supplied adjoint: out6[p] = sum_ij W_ij dK~_p,ij +
@@ -1107,6 +1613,22 @@ int gpfit_fit_eval_f32(gpfit_ctx* c, void* stream, const double* theta, const do
 
 int gpfit_fit_eval_finish(gpfit_ctx* c, double* out_host) { return fit_eval_finish(c, out_host); }
 
+int gpfit_fit_eval_batch(gpfit_ctx* const* ctxs, int n_units, void* stream, const double* theta, const double* lower,
+                         const double* upper, int n_rows, int n_cols, const double* const* X, int64_t ldx, int64_t N,
+                         const double* const* r, const double* const* m, const double* const* V, int64_t ldv,
+                         const double* logA, const double* lambda0, int want_grad, double* out_host, int* rc_out) {
+  return fit_eval_batch_impl<double>(ctxs, n_units, stream, theta, lower, upper, n_rows, n_cols, X, ldx, N, r, m, V, ldv,
+                                     logA, lambda0, want_grad, out_host, rc_out);
+}
+
+int gpfit_fit_eval_batch_f32(gpfit_ctx* const* ctxs, int n_units, void* stream, const double* theta, const double* lower,
+                             const double* upper, int n_rows, int n_cols, const float* const* X, int64_t ldx, int64_t N,
+                             const float* const* r, const float* const* m, const float* const* V, int64_t ldv,
+                             const double* logA, const double* lambda0, int want_grad, double* out_host, int* rc_out) {
+  return fit_eval_batch_impl<float>(ctxs, n_units, stream, theta, lower, upper, n_rows, n_cols, X, ldx, N, r, m, V, ldv,
+                                    logA, lambda0, want_grad, out_host, rc_out);
+}
+
 int gpfit_fit_eval_projected(gpfit_ctx* c, void* stream, const double* theta, const double* lower, const double* upper,
                              int n_rows, int n_cols, const double* X, int64_t ldx, int64_t N, const double* r,
                              const double* B, int64_t ldb, int64_t n_kept, const double* m_b, const double* V_b,
@@ -1188,12 +1710,7 @@ int gpfit_ctx_create(int device, int64_t n_max, int64_t d_max, int64_t d_full_ma
     if (e && atoi(e) == 0) GP_HIP(hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking));
     else GP_HIP(hipStreamCreateWithPriority(&c->aux, hipStreamNonBlocking, least));
   }
-  {
-    // side streams of the two chains: off the critical path, lowest priority
-    int least = 0, greatest = 0;
-    GP_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
-    for (int i = 0; i < 2; ++i) GP_HIP(hipStreamCreateWithPriority(&c->side[i], hipStreamNonBlocking, least));
-  }
+  // (the side streams of the two chains are created on first use: ensure_side_streams)
   GP_HIP(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
   GP_HIP(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
   // the strict-upper tiles of every triangular work matrix are never written and must read as 0

@@ -53,9 +53,17 @@ __device__ __forceinline__ bool gemm_tile_compute(const GemmArgsT<R>& p, int til
   row0 = ti * T;
   col0 = tj * T;
   const int b = blockIdx.y, z = blockIdx.z;
-  const R* A = p.A + (int64_t)b * p.sA;
-  const R* B = p.B + (int64_t)b * p.sB;
-  C = p.C + (int64_t)b * p.sC;
+  const R* A;
+  const R* B;
+  if (p.nptr > 0) {
+    A = p.Ap[b];
+    B = p.Bp[b];
+    C = p.Cp[b];
+  } else {
+    A = p.A + (int64_t)b * p.sA;
+    B = p.B + (int64_t)b * p.sB;
+    C = p.C + (int64_t)b * p.sC;
+  }
 
   int kbeg = 0, kend = p.K;
   if (p.a_tri == 1) kend = min(kend, row0 + T);
@@ -98,7 +106,8 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgsT<R>& p, int tiles_
     // fused epilogues (common.h: 1 mirror, 2 tile norms, 4 dual update); the launcher has checked that the
     // launch is data-parallel on full tiles
     constexpr int epi = EPI;
-    R* __restrict__ D = p.aux;
+    R* __restrict__ D = p.nptr > 0 ? p.auxp[blockIdx.y] : p.aux;
+    double* __restrict__ sumsq = p.nptr > 0 ? p.sumsqp[blockIdx.y] : p.sumsq;
     double ss = 0.0;
     for_each_acc<R, T>(acc, row0, col0, [&](int row, int col, R v) {
       if (EDGE && !(row < M && col < N)) return;
@@ -128,7 +137,7 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgsT<R>& p, int tiles_
       __syncthreads();  // every wave is done with the operand stages
       if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ss;
       __syncthreads();
-      if (threadIdx.x == 0) p.sumsq[(int64_t)ti * (ti + 1) / 2 + tj] = (red[0] + red[1]) + (red[2] + red[3]);
+      if (threadIdx.x == 0) sumsq[(int64_t)ti * (ti + 1) / 2 + tj] = (red[0] + red[1]) + (red[2] + red[3]);
     }
     return;
   }
@@ -204,11 +213,17 @@ int gemm_pick_tile(const GemmArgsT<R>& a) {
   auto ntiles = [&](int T) {
     const long tm = (a.M + T - 1) / T, tn = (a.N + T - 1) / T;
     const long nb = (a.M + TILE - 1) / TILE;
-    return (a.out_lower ? (long)lower_tile_count((int)nb, TILE / T) : tm * tn) * (a.batch > 0 ? a.batch : 1) *
+    return (a.out_lower ? (long)lower_tile_count((int)nb, TILE / T) : tm * tn) * (a.nptr > 0 ? a.nptr : (a.batch > 0 ? a.batch : 1)) *
            (a.split_k > 1 ? a.split_k : 1);
   };
   static const long t128_min = getenv("GPFIT_T128_MIN") ? atol(getenv("GPFIT_T128_MIN")) : 384;
-  if (ntiles(128) >= t128_min) return 128;
+  // pointer batches with triangular operands: the tiles' k ranges differ by up to the matrix size and a batch has
+  // no balanced (stream-K / table) schedule, so the 128-tile only pays once the launch runs for several rounds of
+  // the chip (measured at 2048-sized blocks, executed TF/s: two problems 37-39 on 128-tiles against 54 on
+  // 64-tiles launched one by one; four problems 55)
+  static const long t128_tri_min = getenv("GPFIT_T128_TRI_MIN") ? atol(getenv("GPFIT_T128_TRI_MIN")) : 1024;
+  const bool batch_tri = a.nptr > 0 && (a.a_tri || a.b_tri);
+  if (ntiles(128) >= (batch_tri ? t128_tri_min : t128_min)) return 128;
   static const long t64_min = getenv("GPFIT_T64_MIN") ? atol(getenv("GPFIT_T64_MIN")) : 256;
   static const long t32_dim = getenv("GPFIT_T32_DIM") ? atol(getenv("GPFIT_T32_DIM")) : 1024;
   if (ntiles(64) >= t64_min) return 64;
@@ -284,15 +299,16 @@ static void launch_T(const GemmArgsT<R>& p, hipStream_t s) {
 
 template <typename R>
 bool gemm_epilogue_ok(const GemmArgsT<R>& a) {
-  if (a.split_k > 1 || a.batch > 1 || a.M <= 0 || a.N <= 0) return false;
+  if (a.split_k > 1 || (a.batch > 1 && a.nptr <= 0) || a.M <= 0 || a.N <= 0) return false;
   const int T = gemm_pick_tile(a);
   if ((a.M % T) || (a.N % T)) return false;                                    // full tiles only
   if ((a.epi & 1) && (!a.out_lower || a.M != a.N)) return false;
   if ((a.epi & 2) && (T != TILE || !a.out_lower)) return false;
-  if ((a.epi & 4) && a.aux == nullptr) return false;
+  if ((a.epi & 4) && a.nptr <= 0 && a.aux == nullptr) return false;
   // instances that exist (launch_T): 128-tile, row-major A, and per mode the operand layout the fit uses
   if (T != TILE || a.a_kmajor || a.half_occ) return false;
   if (!((a.epi == 2 && a.b_kmajor) || (a.epi == 1 && !a.b_kmajor) || (a.epi == 4 && a.b_kmajor))) return false;
+  if (a.nptr > 0) return true;   // pointer batches are always data-parallel
   if (T == TILE && a.tile_limit == 0) {
     if ((a.reverse & 8) && gemm_xcd_applies(a)) return true;
     if (gemm_streamk_applies(a)) return false;
@@ -309,6 +325,7 @@ int launch_gemm(const GemmArgsT<R>& a, hipStream_t s) {
     set_error("launch_gemm: this launch cannot carry a fused epilogue (ask gemm_epilogue_ok first)");
     return -3;
   }
+  if (a.nptr > 0) return launch_gemm_plain(a, s);   // pointer batches are data-parallel launches
   if (a.half_occ) return launch_gemm_plain(a, s);
   if (a.tile_limit == 0 && gemm_pick_tile(a) == TILE && a.batch <= 1) {
     if (a.reverse & 8) {
@@ -336,6 +353,13 @@ int launch_gemm_plain(const GemmArgsT<R>& a, hipStream_t s) {
     return -3;
   }
   GemmArgsT<R> p = a;
+  if (p.nptr > 0) {
+    if (p.nptr > GEMM_MAXB || p.sched || p.split_k > 1) {
+      set_error("launch_gemm: a pointer batch holds at most GEMM_MAXB plain problems");
+      return -3;
+    }
+    p.batch = p.nptr;
+  }
   if (p.batch <= 0) p.batch = 1;
   switch (gemm_pick_tile(p)) {
     case 128: launch_T<R, 128>(p, s); break;

@@ -111,7 +111,7 @@ static int build(const GemmArgsT<R>& a, Plan& plan) {
 
 template <typename R>
 bool gemm_xcd_applies(const GemmArgsT<R>& a) {
-  if ((a.M % TILE) || (a.N % TILE) || a.split_k > 1 || a.batch > 1 || (a.tile && a.tile != TILE)) return false;
+  if ((a.M % TILE) || (a.N % TILE) || a.split_k > 1 || a.batch > 1 || a.nptr > 0 || (a.tile && a.tile != TILE)) return false;
   if (a.out_lower && a.M != a.N) return false;
   const long tm = a.M / TILE, tn = a.N / TILE;
   if (tm >= 32768 || tn >= 32768) return false;

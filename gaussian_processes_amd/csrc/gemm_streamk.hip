@@ -229,7 +229,7 @@ template <typename R>
 static int streamk_first_tile(const GemmArgsT<R>& a) {
   static const bool disabled = getenv("GPFIT_NO_STREAMK") != nullptr;
   if (disabled) return -1;
-  if ((a.M % TILE) || (a.N % TILE) || a.split_k > 1 || a.batch > 1 || (a.tile && a.tile != TILE)) return -1;
+  if ((a.M % TILE) || (a.N % TILE) || a.split_k > 1 || a.batch > 1 || a.nptr > 0 || (a.tile && a.tile != TILE)) return -1;
   const long tm = a.M / TILE, tn = a.N / TILE;
   const int ntiles = (int)(a.out_lower ? tm * (tm + 1) / 2 : tm * tn);
   static const int sk_min = getenv("GPFIT_SK_MIN_TILES") ? atoi(getenv("GPFIT_SK_MIN_TILES")) : 384;

@@ -19,6 +19,19 @@ int launch_chol_leaf(const R* A, int64_t lda, R* L, int64_t ldl, R* Linv, int64_
 template <typename R>
 int launch_chol_leaf_reg(const R* A, int64_t lda, R* L, int64_t ldl, R* Linv, int64_t ldi, int* info, int info_base,
                          hipStream_t s);
+// n independent 128 x 128 blocks in one launch (one workgroup each): block b factors A[b] into L[b], Li[b] and
+// reports into info[b]; common leading dimensions and info_base
+template <typename R>
+struct LeafBatchT {
+  const R* A[GEMM_MAXB];
+  R* L[GEMM_MAXB];
+  R* Li[GEMM_MAXB];
+  int* info[GEMM_MAXB];
+  int64_t lda, ldl, ldi;
+  int info_base;
+  int n;
+};
+template <typename R> int launch_chol_leaf_batch(const LeafBatchT<R>& bt, hipStream_t s);
 
 // ---- elementwise.hip  (templated on the scalar type R = double | float; reductions are always
 //      accumulated and returned in fp64)

@@ -172,6 +172,71 @@ class GPFitEngine:
         }
 
 
+MAX_GROUP = 16  # units per gpfit_fit_eval_batch call (2 chains each; GEMM_MAXB = 32 problems per pointer batch)
+
+
+def fit_eval_group(engines, thetas, lower, upper, n_px_side, X, r, m, V, logA, lambda0, want_grad=True, reuse_V=False,
+                   grad_precision="native"):
+    """``len(thetas)`` independent units of the same N in ONE call (``gpfit_fit_eval_batch``): unit u on
+    ``engines[u]`` with ``thetas[u]``, ``r[u]``, ``m[u]``, ``V[u]`` (``X``, ``r``, ``m``, ``V``, ``logA``, ``lambda0`` may
+    each be one object shared by every unit or a list with one entry per unit).  The Cholesky recursions of all
+    units run in lock step (shared launches on the latency-bound levels); results are bit-identical to
+    ``engines[u].fit_eval`` unit by unit.  Returns the list of result dicts of :meth:`GPFitEngine.fit_eval`
+    (without the per-point vectors)."""
+    nu = len(thetas)
+    if not 1 <= nu <= MAX_GROUP or len(engines) < nu:
+        raise ValueError(f"fit_eval_group: 1 .. {MAX_GROUP} units per call, one engine per unit")
+    e0 = engines[0]
+    rows, cols = _grid(n_px_side)
+
+    def per_unit(x):
+        return list(x) if isinstance(x, (list, tuple)) else [x] * nu
+
+    Xs, rs, ms, Vs = per_unit(X), per_unit(r), per_unit(m), per_unit(V)
+    dtype = Xs[0].dtype if Xs[0].dtype == torch.float32 else torch.float64
+    Xs = [e0._dev(t, "X", dtype) for t in Xs]
+    rs = [e0._dev(t, "r", dtype) for t in rs]
+    ms = [e0._dev(t, "m", dtype) for t in ms]
+    Vs = [e0._dev(t, "V", dtype) for t in Vs]
+    N = Xs[0].shape[0]
+    if any(t.shape != Xs[0].shape or t.stride(0) != Xs[0].stride(0) for t in Xs) or Xs[0].shape[1] != rows * cols:
+        raise ValueError("fit_eval_group: every unit needs stimuli of the same shape, matching the pixel grid")
+    if any(t.shape != (N, N) or t.stride(0) != Vs[0].stride(0) for t in Vs):
+        raise ValueError("fit_eval_group: every V must be N x N with the same row stride")
+    if grad_precision not in ("native", "f32") or (grad_precision == "f32" and dtype != torch.float64):
+        raise ValueError("grad_precision must be 'native' or, for float64 inputs, 'f32'")
+    logAs = [float(_scalar(v)) for v in per_unit(logA)]
+    lam0s = [float(_scalar(v)) for v in per_unit(lambda0)]
+    ctxs = (ctypes.c_void_p * nu)(*[e._ctx for e in engines[:nu]])
+
+    def ptrs(ts):
+        return (ctypes.c_void_p * nu)(*[t.data_ptr() for t in ts])
+
+    theta = _lib.darr([v for th in thetas for v in theta_vec(th)])
+    lo = _lib.darr(theta_vec(lower)) if lower is not None else None
+    up = _lib.darr(theta_vec(upper)) if upper is not None else None
+    out = (ctypes.c_double * (16 * nu))()
+    rcs = (ctypes.c_int * nu)()
+    flags = (1 if want_grad else 0) | (2 if reuse_V else 0) | (8 if grad_precision == "f32" else 0)
+    entry = e0.lib.gpfit_fit_eval_batch_f32 if dtype == torch.float32 else e0.lib.gpfit_fit_eval_batch
+    rc = entry(ctxs, nu, e0._stream(), theta, lo, up, rows, cols, ptrs(Xs), Xs[0].stride(0), N, ptrs(rs), ptrs(ms), ptrs(Vs),
+               Vs[0].stride(0), _lib.darr(logAs), _lib.darr(lam0s), flags, out, rcs)
+    _lib.check(rc, "gpfit_fit_eval_batch")
+    results, first_error = [], None
+    for u in range(nu):   # every pending unit is collected, also behind a failed one
+        o = (ctypes.c_double * 16)(*out[16 * u:16 * u + 16])
+        ticket = {"rc": int(rcs[u]), "out": o, "pending": rcs[u] == 0, "keep": (Xs[u], rs[u], ms[u], Vs[u]),
+                  "lam_m": None, "lam_var": None, "f": None}
+        try:
+            results.append(engines[u].fit_eval_finish(ticket))
+        except _lib.GpfitError as err:
+            results.append(None)
+            first_error = first_error or err
+    if first_error is not None:
+        raise first_error
+    return results
+
+
 def fits_flops(N: int, d: int) -> float:
     """Algorithmic flops of one unit of work, SURVEY.md 8(d): (14/3)N^3 + 4N^2 d + 4 N d^2."""
     return (14.0 / 3.0) * N ** 3 + 4.0 * N * N * d + 4.0 * N * d * d

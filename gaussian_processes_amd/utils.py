@@ -7,8 +7,8 @@ hand-written HIP library ``libgpfit_mi355x.so`` through ctypes.  torch supplies 
 memory, streams and (for the rank decision only) ``torch.linalg.eigh``.
 
 There is no CPU fallback: without a GPU or without the built library every entry point raises.
-``save_model`` / ``load_model`` keep the reference's on-disk layout (model_io.py).
-Out of scope (SURVEY.md section 2 rows 10-14,16-19): plotting, the dataset container, and the
+Out of scope (SURVEY.md section 2 rows 10-14,16-19): plotting, persistence (``save_model`` / ``load_model``: the
+reference's own functions pickle the ``fit_model`` dict this module returns), the dataset container, and the
 reference's dead code (``utility`` / ``get_utility`` scalar variants, ``block_matrix_inverse``, ``updateA``,
 ``linker``: no caller in the reference's own files).
 """
@@ -24,7 +24,6 @@ import torch
 
 from . import _lib
 from .engine import GPFitEngine, _grid, theta_vec
-from .model_io import load_model, save_model  # noqa: F401  (utils.py:46, 312)
 from . import eigtop
 from .synthetic import THETA_KEYS
 
@@ -709,7 +708,7 @@ def _all_eigenvalues_kept(K_tilde):
     return lam_min_lb > max(lam_max_ub * EIGVAL_TOL, EIGVAL_TOL), L, Li
 
 
-def _stabilised_basis(K_tilde):
+def _stabilised_basis(K_tilde, route=None):
     """Basis the reference works in after its eigen-stabilisation (utils.py:1682-1694): returns
     ``(eigvecs, B, K_tilde_b, K_tilde_inv_b)``.
 
@@ -720,50 +719,85 @@ def _stabilised_basis(K_tilde):
     N >= 4096, the kept eigenpairs come from block subspace iteration (``eigtop.top_eigenpairs``) and the
     first return value holds only those columns; otherwise, and whenever that solver declines, the
     reference's own eigendecomposition + truncation.  Every route is a deterministic function of K~, so
-    ``test(at_iteration=...)`` rebuilds the basis the tracked ``(m_b, V_b)`` were expressed in."""
-    n = K_tilde.shape[0]
-    if not _FORCE_EIGH:
-        def truncated_basis():
-            # truncated regime: only the kept eigenpairs, by block subspace iteration on the library's GEMM and
-            # Cholesky (eigtop.py; 105 ms against 670 ms for the full eigh at N = 8192, same eigenvalues to
-            # 1e-14 and the same invariant subspace to 1e-13).  None: inconclusive -> the reference's own eigh.
-            top = eigtop.top_eigenpairs(K_tilde, EIGVAL_TOL, matmul, cholesky) if n >= _EIGTOP_MIN_N else None
-            if top is None:
-                return None
-            vals, vecs, _ = top
-            # the first entry stands in for the reference's N x N eigenvector matrix: only the kept columns exist
-            return vecs, vecs, torch.diag(vals), torch.diag_embed(1 / vals)
+    ``test(at_iteration=...)`` rebuilds the basis the tracked ``(m_b, V_b)`` were expressed in.
 
+    The route taken (``'identity'``, ``'eigtop'`` or ``'eigh'``) is left in ``_BASIS.route`` (per host thread);
+    ``varGP`` records it with every tracked iteration.  ``route=...`` asks for exactly that route -- what
+    ``test(at_iteration=...)`` does with the recorded one, so that a model fitted under one setting
+    (``GPFIT_FORCE_EIGH``, another library version) is never evaluated in a different basis: a route that
+    cannot be reproduced raises instead of returning numbers in the wrong coordinates."""
+    n = K_tilde.shape[0]
+
+    def truncated_basis():
+        # truncated regime: only the kept eigenpairs, by block subspace iteration on the library's GEMM and
+        # Cholesky (eigtop.py; 105 ms against 670 ms for the full eigh at N = 8192, same eigenvalues to
+        # 1e-14 and the same invariant subspace to 1e-13).  None: inconclusive -> the reference's own eigh.
+        top = eigtop.top_eigenpairs(K_tilde, EIGVAL_TOL, matmul, cholesky) if n >= _EIGTOP_MIN_N else None
+        if top is None:
+            return None
+        vals, vecs, _ = top
+        # the first entry stands in for the reference's N x N eigenvector matrix: only the kept columns exist
+        return vecs, vecs, torch.diag(vals), torch.diag_embed(1 / vals)
+
+    def identity_basis(Li):
+        B = _mark_identity(torch.eye(n, dtype=TORCH_DTYPE, device=K_tilde.device))
+        Kinv = matmul(Li, Li, transA=True)
+        return None, B, K_tilde, (Kinv + Kinv.T) * 0.5
+
+    def eigh_basis():
+        eigvals, eigvecs, ikeep = _eigen_stabilise(K_tilde)
+        kept = eigvals[ikeep]
+        return eigvecs, eigvecs[:, ikeep].contiguous(), torch.diag(kept), torch.diag_embed(1 / kept)
+
+    if route is not None:
+        if route == "identity":
+            kept, _, Li = _all_eigenvalues_kept(K_tilde)
+            out = identity_basis(Li) if kept else None
+        elif route == "eigtop":
+            out = truncated_basis()
+        elif route == "eigh":
+            out = eigh_basis()
+        else:
+            raise ValueError(f"unknown basis route {route!r}")
+        if out is None:
+            raise _lib.GpfitError(f"the basis route {route!r} recorded with this model cannot be reproduced for this "
+                                  "kernel matrix (EIGVAL_TOL or the library changed since the fit)")
+        _BASIS.route = route
+        return out
+    if not _FORCE_EIGH:
         # The two checks agree on every K~ (a proof that all eigenvalues are kept excludes a truncated count and
         # vice versa), so their order only decides what is paid: a kernel matrix of this size that was truncated
-        # last time (the same fit, one EM iteration later) goes to the subspace solver first and skips the
-        # Cholesky + inverse + norms of the all-kept proof (~25 ms at N = 8192).
+        # last time ON THIS THREAD (the same fit, one EM iteration later) goes to the subspace solver first and
+        # skips the Cholesky + inverse + norms of the all-kept proof (~25 ms at N = 8192).
+        hints = _BASIS.__dict__.setdefault("regime", {})
         key = (n, float(EIGVAL_TOL))
-        if _LAST_REGIME.get(key) == "truncated":
+        if hints.get(key) == "truncated":
             out = truncated_basis()
             if out is not None:
+                _BASIS.route = "eigtop"
                 return out
         kept, L, Li = _all_eigenvalues_kept(K_tilde)
         if kept:
-            _LAST_REGIME[key] = "full"
-            B = _mark_identity(torch.eye(n, dtype=TORCH_DTYPE, device=K_tilde.device))
-            Kinv = matmul(Li, Li, transA=True)
-            return None, B, K_tilde, (Kinv + Kinv.T) * 0.5
-        if _LAST_REGIME.get(key) != "truncated":
+            hints[key] = "full"
+            _BASIS.route = "identity"
+            return identity_basis(Li)
+        if hints.get(key) != "truncated":
             out = truncated_basis()
             if out is not None:
-                _LAST_REGIME[key] = "truncated"
+                hints[key] = "truncated"
+                _BASIS.route = "eigtop"
                 return out
-    eigvals, eigvecs, ikeep = _eigen_stabilise(K_tilde)
-    B = eigvecs[:, ikeep].contiguous()
-    kept = eigvals[ikeep]
-    return eigvecs, B, torch.diag(kept), torch.diag_embed(1 / kept)
+    _BASIS.route = "eigh"
+    return eigh_basis()
 
 
 import os as _os_mod
 _FORCE_EIGH = bool(_os_mod.environ.get("GPFIT_FORCE_EIGH"))   # tuning / A-B knob: always take the eigh route
 _EIGTOP_MIN_N = 4096   # below this the full eigh is as fast (N = 3072: 91 ms either way)
-_LAST_REGIME = {}      # (N, EIGVAL_TOL) -> "full" | "truncated": which of the two rank checks to try first
+# per host thread (the reference's active-learning notebook fits and scores on two threads): the route the last
+# call of _stabilised_basis took, and (N, EIGVAL_TOL) -> "full" | "truncated", which of the two rank checks to try
+# first -- a hint only, so one thread's history never changes what another thread's fit costs
+_BASIS = threading.local()
 
 
 def _closure_general(theta, lims, n_px_side, x, xtilde, r, B, m_b, V_b, f_params, ntilde, nt):
@@ -998,7 +1032,16 @@ def varGP(x, r, **kwargs):
     north-star configurations) the M-step closure is ONE call of the fused HIP unit of work
     (``gpfit_fit_eval``) and the E-step ONE call of ``gpfit_estep`` in the original basis;
     otherwise the same steps run in the reference's projected formulation on the GPU
-    primitives."""
+    primitives.
+
+    Deviations from the reference's ``fit_model``, both additive or opt-out:
+    * ``final_kernel['eigvecs']`` (utils.py:2241: the N x N eigenvector matrix of K~) is ``None`` when every
+      eigenvalue was kept (no eigendecomposition is computed on that route) and holds only the kept columns when
+      the subspace solver built the basis (N >= 4096, truncated spectrum); ``fit_parameters['full_eigvecs'] =
+      True`` asks for the reference's full matrix (one ``torch.linalg.eigh`` of the final K~ at the end of the fit).
+    * extra keys: ``fit_model['basis_route']`` and ``values_track['variation_par_track']['basis_route']``
+      (``'identity'`` / ``'eigtop'`` / ``'eigh'`` per tracked iteration): the route that built the basis ``(m_b,
+      V_b)`` are expressed in, which ``test(at_iteration=...)`` reproduces or refuses."""
     import time
     start_time_before_init = time.time()
     err_dict = {'is_error': False, 'error_message': None}
@@ -1050,8 +1093,11 @@ def varGP(x, r, **kwargs):
         Kv = kernfun(th, x_m, x2=None, C=C_, dC=None, diag=True)
         return C_, mask_, Kt, K_, Kv, x_m
 
+    basis_route = [None]   # route of the basis in force (recorded with every tracked iteration)
+
     def project(Kt, K_):
         eigvecs_, B_, Ktb, Ktib = _stabilised_basis(Kt)
+        basis_route[0] = _BASIS.route
         if _is_identity(B_):
             Kb = K_
             a_ = matmul(Kb, Ktib) if ntilde != nt else B_
@@ -1108,7 +1154,7 @@ def varGP(x, r, **kwargs):
     l0key = 'lambda0' if 'lambda0' in f_params else 'loglambda0'
     f_par_track = {'logA': torch.zeros(maxiter), l0key: torch.zeros(maxiter)}
     values_track = {'loss_track': loss_track, 'theta_track': theta_track, 'f_par_track': f_par_track,
-                    'variation_par_track': {'V_b': (), 'm_b': ()}}
+                    'variation_par_track': {'V_b': (), 'm_b': (), 'basis_route': ()}}
 
     def record(it):
         loss_track['loglikelihood'][it] = _scalar(loglikelihood)
@@ -1120,6 +1166,7 @@ def varGP(x, r, **kwargs):
         f_par_track[l0key][it] = _scalar(f_params[l0key])
         values_track['variation_par_track']['V_b'] += (V_b.clone(),)
         values_track['variation_par_track']['m_b'] += (m_b.clone(),)
+        values_track['variation_par_track']['basis_route'] += (basis_route[0],)
 
     times = {'estep': 0.0, 'fparams': 0.0, 'mstep': 0.0, 'kernels': 0.0, 'loss': 0.0}
     start_time_loop = time.time()
@@ -1298,6 +1345,8 @@ def varGP(x, r, **kwargs):
         loss_track['KL'][last] = _scalar(KL_div)
         loss_track['logmarginal'][last] = _scalar(logmarginal)
 
+    if fit_parameters.get('full_eigvecs', False) and (eigvecs is None or eigvecs.shape[1] != eigvecs.shape[0]):
+        eigvecs = torch.linalg.eigh(K_tilde, UPLO='L')[1]     # the reference's N x N matrix, on request (utils.py:2241)
     final_kernel = {'C': C, 'mask': mask, 'K_tilde': K_tilde, 'K': K, 'Kvec': Kvec, 'eigvecs': eigvecs}
     if not is_simmetric(V_b, 'V_b'):
         print('Final V_b is not simmetric, maximum difference: ', torch.max(torch.abs(V_b - V_b.T)))
@@ -1326,7 +1375,7 @@ def varGP(x, r, **kwargs):
         'fit_parameters': fit_parameters, 'final_kernel': final_kernel, 'err_dict': err_dict, 'xtilde': xtilde,
         'hyperparams_tuple': (theta, theta_lower_lims, theta_higher_lims), 'f_params': f_params, 'm_b': m_b,
         'V_b': V_b, 'C': C, 'mask': mask, 'K_tilde_b': K_tilde_b, 'K_tilde_inv_b': K_tilde_inv_b, 'K_b': K_b,
-        'Kvec': Kvec, 'B': B, 'values_track': values_track,
+        'Kvec': Kvec, 'B': B, 'values_track': values_track, 'basis_route': basis_route[0],
     }
     return fit_model, err_dict
 
@@ -1361,7 +1410,8 @@ def test(X_test, R_test, xtilde, X_train=None, at_iteration=None, **kwargs):
                            n_px_side=n_px_side, grad=False)
         xt_m = xtilde[:, mask].contiguous()
         Kt = acosker(theta, xt_m, xt_m, C=C, diag=False)
-        _, B, K_tilde, K_tilde_inv = _stabilised_basis(Kt)
+        routes = vt['variation_par_track'].get('basis_route')     # absent in a dict the reference itself produced
+        _, B, K_tilde, K_tilde_inv = _stabilised_basis(Kt, route=routes[at_iteration] if routes else None)
 
     X_test = _cu(X_test)
     n_img = X_test.shape[0]
@@ -1375,24 +1425,3 @@ def test(X_test, R_test, xtilde, X_train=None, at_iteration=None, **kwargs):
     print(f"\n\n Pietro's model: R2 = {float(r2):.2f} ± {float(sigma_r2):.2f} Cell: {cellid} maxiter = {maxiter}, "
           f"nEstep = {nEstep}, nMstep = {nMstep} \n")
     return R_test[:, :, cellid], R_predicted, r2, sigma_r2
-
-
-# ------------------------------------------------------------------ names of the reference that are not provided
-_NOT_PROVIDED = {
-    "plot_loss_and_theta_notebook": "plotting helper (utils.py:111): call the reference's own function on the fit_model dict "
-                                    "this module returns -- the schema is the same",
-    "plot_fit": "plotting helper (utils.py:1543)",
-    "save_pickle": "writes into the reference's own data/ directory (utils.py:689)",
-    "utility": "scalar form of nd_utility (utils.py:596): use nd_utility, which accepts 0-d inputs",
-    "get_utility": "no caller in the reference, and its own call of lambda_moments_star does not match that function's signature (utils.py:619-629)",
-    "block_matrix_inverse": "no caller in the reference (utils.py:1055); cholesky_append is the rank-1 update of this module",
-    "updateA": "no caller in the reference (utils.py:1339)",
-    "linker": "no caller in the reference (utils.py:916)",
-}
-
-
-def __getattr__(name):
-    if name in _NOT_PROVIDED:
-        raise AttributeError(f"gaussian_processes_amd.utils does not provide {name!r}: {_NOT_PROVIDED[name]} "
-                             "(out of the scope of the fit path, DESIGN.md section 8)")
-    raise AttributeError(f"module {__name__!r} has no attribute {name!r}")

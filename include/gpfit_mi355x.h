@@ -142,6 +142,28 @@ int gpfit_fit_eval(gpfit_ctx* ctx, void* stream, const double* theta, const doub
  * would have returned (0 or the LAPACK info).  -3 if nothing is pending. */
 int gpfit_fit_eval_finish(gpfit_ctx* ctx, double* out_host);
 
+/* n_units (1 .. 16) independent units of work of the same N in one call -- the cells / hyperparameter-grid
+ * points of BASELINE configs[3], [4] (no dependency between units), unit u on its own context
+ * ctxs[u] with theta[6 u ..], X[u], r[u], m[u], V[u] (device pointers; X may be the same matrix for every
+ * unit), logA[u], lambda0[u].  Replaces n_units calls of the closure utils.py:2017-2112.  Everything runs on
+ * `stream`: the 2 n_units Cholesky recursions in lock step (their latency-bound leaves and small products are
+ * shared launches), the products behind them as pointer-batched launches wherever one unit's product cannot
+ * fill the chip.  Each unit's results are bit-identical to gpfit_fit_eval on its own.  want_grad: bits 0, 1, 3
+ * as gpfit_fit_eval; the call is always asynchronous: rc_out[u] = 0 -> collect unit u with
+ * gpfit_fit_eval_finish(ctxs[u], ...); -2 -> theta outside the limits, out_host[16 u ..] already holds the
+ * infinite loss / gradients and nothing is pending.  Returns 0 or < 0 (bad argument / capacity / HIP error). */
+int gpfit_fit_eval_batch(gpfit_ctx* const* ctxs, int n_units, void* stream, const double* theta,
+                         const double* lower, const double* upper, int n_rows, int n_cols,
+                         const double* const* X, int64_t ldx, int64_t N, const double* const* r,
+                         const double* const* m, const double* const* V, int64_t ldv, const double* logA,
+                         const double* lambda0, int want_grad, double* out_host, int* rc_out);
+/* The same for the fp32 instance of the library (gpfit_fit_eval_f32). */
+int gpfit_fit_eval_batch_f32(gpfit_ctx* const* ctxs, int n_units, void* stream, const double* theta,
+                             const double* lower, const double* upper, int n_rows, int n_cols,
+                             const float* const* X, int64_t ldx, int64_t N, const float* const* r,
+                             const float* const* m, const float* const* V, int64_t ldv, const double* logA,
+                             const double* lambda0, int want_grad, double* out_host, int* rc_out);
+
 /* Gradient pull-back for an externally supplied adjoint: out_host[6] (theta dict order) =
  *   sum_ij W_ij dK~_p,ij + sum_i gvec_i dKvec_p,i
  * with the reference's analytic derivatives dK~_p (acosker, utils.py:996-1021) and dKvec_p

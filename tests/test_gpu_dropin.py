@@ -417,7 +417,7 @@ def test_fparam_functions(gp):
     assert abs(out[1] - float(Lo)) < 1e-11 * abs(float(Lo)) and abs(out[2] - float(do["logA"])) < 1e-10 * abs(out[2])
 
 
-def _run_vargp(gp, g, at_iteration=None):
+def _run_vargp(gp, g, at_iteration=None, **extra_fit_parameters):
     N, d = int(g["N"]), int(g["d"])
     X = T(g["X"])
     r = T(g["r"])
@@ -425,6 +425,7 @@ def _run_vargp(gp, g, at_iteration=None):
     fit_parameters = {"ntilde": ntilde, "maxiter": int(g["maxiter"]), "nEstep": int(g["nEstep"]), "nMstep": int(g["nMstep"]),
                       "nFparamstep": int(g["nFparamstep"]), "kernfun": "acosker", "cellid": 0, "n_px_side": 8,
                       "display_hyper": False}
+    fit_parameters.update(extra_fit_parameters)
     xtilde = X if ntilde == N else X[:ntilde].clone()
     args = {"fit_parameters": fit_parameters, "xtilde": xtilde, "hyperparams_tuple": (tth(g["theta0"]), LOWER, UPPER),
             "f_params": {"logA": torch.tensor(syn.F_PARAMS["logA"], dtype=torch.float64),
@@ -476,16 +477,17 @@ def test_predict_at_iteration_matches_reference(gp, name):
 
 
 def test_saved_model_predicts_like_the_live_one(gp, tmp_path):
-    """save_model -> load_model(map_location=cuda) -> test(**model) (the notebooks' sequence,
-    one_cell_fit.ipynb) reproduces the live fit's prediction bit for bit; the description carries the
-    tracked start -> end values."""
+    """Persistence is out of scope, but the ``fit_model`` dict must survive it: written with
+    ``torch.save`` and read back with the loader that executes nothing from the file
+    (``torch.load(..., weights_only=True)``: the dict holds tensors, numbers, strings, tuples and dicts only),
+    ``test(**model)`` reproduces the live fit's prediction bit for bit."""
     import os
     g = load_golden("g6_vargp_trunc_N128.npz")
     fit, err, R_pred = _run_vargp(gp, g)
-    target = os.path.join(tmp_path, "saved_fit")
-    gp.save_model(fit, target, additional_description="g6 trunc")
-    back = gp.load_model(target, map_location="cuda:0")
-    assert "Model Description" in back["description"] and "g6 trunc" in back["description"]
+    target = os.path.join(tmp_path, "saved_fit.pt")
+    torch.save(fit, target)
+    back = torch.load(target, map_location="cuda:0", weights_only=True)
+    assert set(back) == set(fit)
     old = gp.EIGVAL_TOL
     gp.EIGVAL_TOL = float(g["tol"])
     try:
@@ -740,7 +742,14 @@ def test_rank_decision_without_eigh(gp):
     # (d) whole fit, identity basis vs forced eigh
     g = load_golden("g6_vargp_full_N128.npz")
     fit_a, err_a, R_a = _run_vargp(gp, g)
-    assert gp._is_identity(fit_a["B"]) and fit_a["final_kernel"]["eigvecs"] is None
+    assert gp._is_identity(fit_a["B"]) and fit_a["final_kernel"]["eigvecs"] is None and fit_a["basis_route"] == "identity"
+    # the reference's schema (utils.py:2241: the N x N eigenvector matrix of the final K~) on request
+    fit_e, _, R_e = _run_vargp(gp, g, full_eigvecs=True)
+    P = fit_e["final_kernel"]["eigvecs"]
+    Kt = fit_e["final_kernel"]["K_tilde"]
+    assert P.shape == Kt.shape and torch.equal(R_e, R_a)
+    lam = torch.diagonal(P.T @ Kt @ P)
+    assert relerr(((P * lam) @ P.T).cpu().numpy(), Kt.cpu().numpy()) < 1e-10 and relerr((P.T @ P).cpu().numpy(), np.eye(P.shape[0])) < 1e-10
     gp._FORCE_EIGH = True
     try:
         fit_b, err_b, R_b = _run_vargp(gp, g)
@@ -844,7 +853,7 @@ def test_vargp_with_the_subspace_basis_tracks_the_eigh_route(gp):
                              "lambda0": torch.tensor(syn.F_PARAMS["lambda0"], dtype=torch.float64)}}
         old = gp._FORCE_EIGH
         gp._FORCE_EIGH = force
-        gp._LAST_REGIME.clear()
+        gp._BASIS.__dict__.pop("regime", None)
         try:
             with contextlib.redirect_stdout(io.StringIO()), warnings.catch_warnings():
                 warnings.simplefilter("ignore")
@@ -859,6 +868,24 @@ def test_vargp_with_the_subspace_basis_tracks_the_eigh_route(gp):
     a, Ra, Ra1 = run(False)
     b, Rb, Rb1 = run(True)
     assert a["B"].shape == b["B"].shape and 100 < a["B"].shape[1] < N // 4
+    # the route that built each tracked basis is part of the model ...
+    assert a["basis_route"] == "eigtop" and b["basis_route"] == "eigh"
+    assert set(a["values_track"]["variation_par_track"]["basis_route"]) == {"eigtop"}
+    assert set(b["values_track"]["variation_par_track"]["basis_route"]) == {"eigh"}
+    # ... and test(at_iteration) follows it whatever the process-wide setting says: the eigh-fitted model evaluated
+    # with the subspace solver enabled still goes through eigh (Rb1 above was computed with it forced; same bits)
+    with contextlib.redirect_stdout(io.StringIO()), warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        _, Rb1_again, _, _ = gp.test(Xs, Rt, X_train=X, at_iteration=1, **b)
+    assert torch.equal(Rb1_again, Rb1)
+    # a route that cannot be reproduced is refused, not silently replaced
+    broken = dict(a)
+    vt = dict(a["values_track"]); vp = dict(vt["variation_par_track"]); vp["basis_route"] = ("identity",) * len(vp["basis_route"])
+    vt["variation_par_track"] = vp; broken["values_track"] = vt
+    with pytest.raises(gp._lib.GpfitError, match="cannot be reproduced"), contextlib.redirect_stdout(io.StringIO()):
+        gp.test(Xs, Rt, X_train=X, at_iteration=1, **broken)
+    # the eigenvector matrix of the reference's schema on request (utils.py:2241)
+    assert a["final_kernel"]["eigvecs"].shape == a["B"].shape and b["final_kernel"]["eigvecs"].shape == (N, N)
     la, lb = a["values_track"]["loss_track"]["logmarginal"].numpy(), b["values_track"]["loss_track"]["logmarginal"].numpy()
     assert relerr(la, lb) < 1e-8, (la, lb)
     ta = np.array([float(a["hyperparams_tuple"][0][k]) for k in KEYS]); tb = np.array([float(b["hyperparams_tuple"][0][k]) for k in KEYS])
