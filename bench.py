@@ -36,7 +36,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 from gaussian_processes_amd import multi, synthetic as syn  # noqa: E402
-from gaussian_processes_amd.engine import GPFitEngine, fits_flops  # noqa: E402
+from gaussian_processes_amd.engine import GPFitEngine, fit_eval_group, fits_flops  # noqa: E402
 
 FP64_MFMA_PEAK_TFLOPS = 78.6  # MI355X dense fp64 matrix peak (AMD datasheet; rocBLAS dgemm reaches 76.7 on-box)
 NOMINAL_GHZ = 2.4                 # MI355X_MICROARCH.md: the clock the peak figures are quoted at
@@ -212,13 +212,18 @@ def main():
     ap.add_argument("--d", type=int, default=0, help="override d")
     ap.add_argument("--cells", type=int, default=64)
     ap.add_argument("--grid-points", type=int, default=512)
+    ap.add_argument("--group", type=int, default=None,
+                    help="independent units per grouped call (gpfit_fit_eval_batch: their factorisations in lock step, "
+                         "batched launches); default 16 for cells64, 8 for thetagrid; 0 = the pipelined driver of --depth")
     ap.add_argument("--depth", type=int, default=None,
-                    help="independent units kept in flight per GPU (default: 3 for cells64 and thetagrid)")
+                    help="with --group 0: independent units kept in flight per GPU on as many contexts (default 3)")
     ap.add_argument("--cpu-sample-n", type=int, default=4096)
     ap.add_argument("--cpu-quick", action="store_true", help="skip the real N=8192 CPU evaluation (about 90 s)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-in-flight", action="store_true", help="skip the informational leg with independent cells in flight")
     ap.add_argument("--no-grad", action="store_true", help="forward-only unit (not the headline metric)")
+    ap.add_argument("--no-accuracy-check", action="store_true",
+                    help="thetagrid in a reduced-precision mode: skip the fp64 sweep of the same lattice after the timed region")
     ap.add_argument("--dtype", choices=["f64", "f32", "mixed"], default=None,
                     help="f64 = the reference's precision; mixed = fp64 factorisations and loss, fp32 gradient products "
                          "(the theta-grid configuration's default: the all-fp32 instance misses the 1e-5 bar on part of "
@@ -227,6 +232,8 @@ def main():
     args.depth_given = args.depth is not None
     if args.depth is None:
         args.depth = 3   # measured optimum for both configs this round (cells64: 148 / 183 / 168 / 166 / 168 cells/s at 2..6)
+    if args.group is None:
+        args.group = {"cells64": 16, "thetagrid": 8}.get(args.config, 0)
     dtype_name = args.dtype or ("mixed" if args.config == "thetagrid" else "f64")
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -284,9 +291,16 @@ def main():
             rc, mc = syn.cell_inputs(N, c)
             inputs[c] = (torch.from_numpy(rc).to(dev), torch.from_numpy(mc).to(dev), build_V(X, grid, syn.theta0(c), dev),
                          syn.theta_eval(c))
-        engs = [eng] + [GPFitEngine(N, d, device=local_rank) for _ in range(max(1, args.depth) - 1)]
+        n_eng = max(1, args.group) if args.group > 0 else max(1, args.depth)
+        engs = [eng] + [GPFitEngine(N, d, device=local_rank) for _ in range(n_eng - 1)]
         extra_engines = engs[1:]
         streams = [torch.cuda.Stream(device=dev) for _ in engs]
+
+        def group_cells(cs):
+            sel = [inputs[c] for c in cs]
+            res = fit_eval_group(engs, [t[3] for t in sel], lower, upper, grid, X, [t[0] for t in sel], [t[1] for t in sel],
+                                 [t[2] for t in sel], logA, lam0, want_grad=want_grad)
+            return [[o["loss"]] + [o["grad"][k] for k in syn.THETA_KEYS] for o in res]
 
         def submit(c, slot):
             rc, mc, Vc, thc = inputs[c]
@@ -302,7 +316,10 @@ def main():
         table = [None]
 
         def step():
-            table[0] = multi.run_sharded(cells, None, dev, submit_fn=submit, collect_fn=collect, depth=len(engs))
+            if args.group > 0:
+                table[0] = multi.run_sharded(cells, None, dev, group_fn=group_cells, group=args.group)
+            else:
+                table[0] = multi.run_sharded(cells, None, dev, submit_fn=submit, collect_fn=collect, depth=len(engs))
             return {"loss": float(table[0][0, 0])}
     else:  # thetagrid: one cell, 512 theta points, (r, m, V) shared -> broadcast once, V factor reused
         npts = args.grid_points
@@ -315,6 +332,12 @@ def main():
         rd, md, Vd = multi.broadcast_state(r0, m0, V0, N, dev, dtype=tdt)
         Vd = Vd.contiguous()
         Xd = X.to(tdt)
+        if tdt != torch.float64 and not args.no_accuracy_check:
+            # the all-fp32 instance is checked against fp64 evaluations of the same points after the timed region
+            r64, m64, V64 = multi.broadcast_state(r0, m0, V0, N, dev, dtype=torch.float64)
+            V64 = V64.contiguous()
+        else:
+            r64, m64, V64 = rd, md, Vd
         del r0, m0, V0
         mine = multi.partition(npts, world, rank)
         units_per_step, unit_name, scaling = npts, "theta-points", "strong"
@@ -324,10 +347,19 @@ def main():
         # point's latency-bound Cholesky chain runs beside another's large gradient products (each context
         # factors V once and then reuses its own copy of the factor)
         tdepth = max(1, args.depth)
-        engs = [eng] + [GPFitEngine(N, d, device=local_rank) for _ in range(tdepth - 1)]
+        n_eng = max(1, args.group) if args.group > 0 else tdepth
+        engs = [eng] + [GPFitEngine(N, d, device=local_rank) for _ in range(n_eng - 1)]
         extra_engines = engs[1:]
         streams = [torch.cuda.Stream(device=dev) for _ in engs]
         fresh = [True] * len(engs)
+        group_calls = [0]
+
+        def group_points(us):
+            # every context factors V in its first group and reuses its own copy of the factor afterwards
+            res = fit_eval_group(engs, [points[u] for u in us], lower, upper, grid, Xd, rd, md, Vd, logA, lam0, want_grad=want_grad,
+                                 reuse_V=group_calls[0] > 0, grad_precision=gprec)
+            group_calls[0] += 1
+            return [[o["loss"]] + [o["grad"][k] for k in syn.THETA_KEYS] for o in res]
 
         def eval_point(u):
             o = eng.fit_eval(points[u], lower, upper, grid, Xd, rd, md, Vd, logA, lam0, want_grad=want_grad,
@@ -347,11 +379,29 @@ def main():
             return [o["loss"]] + [o["grad"][k] for k in syn.THETA_KEYS]
 
         def step():
-            if tdepth == 1:
+            if args.group > 0:
+                t = multi.run_sharded(npts, None, dev, group_fn=group_points, group=args.group)
+            elif tdepth == 1:
                 t = multi.run_sharded(npts, eval_point, dev)
             else:
                 t = multi.run_sharded(npts, None, dev, submit_fn=submit_point, collect_fn=collect_point, depth=tdepth)
+            last_table[0] = t
             return {"loss": float(t[0, 0])}
+
+        last_table = [None]
+
+        def reference_sweep():
+            """The same lattice in fp64 (the library's reference-precision instance, itself oracle-checked at this size:
+            tests/test_gpu_parity.py), grouped, outside the timed region: the yardstick of the reduced-precision modes."""
+            calls = [0]
+
+            def group64(us):
+                res = fit_eval_group(engs, [points[u] for u in us], lower, upper, grid, X, r64, m64, V64, logA, lam0, want_grad=want_grad,
+                                     reuse_V=calls[0] > 0)
+                calls[0] += 1
+                return [[o["loss"]] + [o["grad"][k] for k in syn.THETA_KEYS] for o in res]
+            g = args.group if args.group > 0 else min(8, len(engs))
+            return multi.run_sharded(npts, None, dev, group_fn=group64, group=min(g, len(engs)))
 
     if rank == 0:
         log(f"config {args.config}: inputs resident; warm-up")
@@ -368,6 +418,19 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     assert math.isfinite(res["loss"]), "benchmark evaluation produced a non-finite loss"
+    accuracy = None
+    if args.config == "thetagrid" and dtype_name != "f64" and not args.no_accuracy_check:
+        # every lattice point of the timed sweep against its fp64 evaluation (north star: 1e-5 relative on the log
+        # marginal likelihood); all ranks hold the gathered tables
+        ref = reference_sweep()
+        got = last_table[0]
+        dev_loss = ((got[:, 0] - ref[:, 0]).abs() / ref[:, 0].abs())
+        gscale = ref[:, 1:].abs().max(dim=1).values
+        dev_grad = ((got[:, 1:] - ref[:, 1:]).abs().max(dim=1).values / gscale)
+        accuracy = {"points_compared": int(got.shape[0]), "max_rel_loss_dev": float(dev_loss.max()), "mean_rel_loss_dev": float(dev_loss.mean()),
+                    "argmax_point": int(dev_loss.argmax()), "max_grad_dev_rel_to_largest_component": float(dev_grad.max()),
+                    "bar": 1e-5, "meets_bar": bool(dev_loss.max() <= 1e-5),
+                    "against": "fp64 instance of this library on the same lattice (oracle-checked at N=8192: tests/test_gpu_parity.py)"}
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
@@ -403,33 +466,53 @@ def main():
         # switches that epilogue off), so its
         # rocprofv3 kernel_stats row is this launch's average.
         npad = -(-N // 128) * 128
+        nt = npad // 128
         dom_flops = float(npad) ** 3 / 3.0
-        dom_tflops = dom_flops / max(prof["largest_gemm_ms"], 1e-9) / 1e9
         rname = "double" if dtype_name == "f64" else "float"   # the dominant launch (T) runs in fp32 in the mixed mode
         if dtype_name == "mixed":
             peak = FP32_MFMA_PEAK_TFLOPS
+        # Which kernel T really is depends on its tile count (gemm.hip: launch_gemm): the XCD-aware data-parallel
+        # schedule from 1536 tiles (with the tile-norm epilogue unless GPFIT_FUSED_EPI switches it off), the stream-K
+        # schedule from 384, a small-tile launch below -- where no 128-tile launch exists and nothing is reported.
+        t_tiles = nt * (nt + 1) // 2
         fused_norm = int(os.environ.get("GPFIT_FUSED_EPI", "7")) & 2
-        dom_name = f"gemm_epi_kernel<{rname}, false, true, 2>" if fused_norm else f"gemm_xcd_kernel<{rname}, false, true>"
+        if t_tiles >= 1536:
+            dom_name = f"gemm_epi_kernel<{rname}, false, true, 2>" if fused_norm else f"gemm_xcd_kernel<{rname}, false, true>"
+            dom_how = "XCD-aware macro-tile schedule"
+        elif t_tiles >= 384:
+            dom_name, dom_how = f"gemm_streamk_kernel<{rname}, false, true>", "stream-K schedule; the live figure includes its fix-up kernel"
+        else:
+            dom_name, dom_how = None, None
+        measured = prof["largest_gemm_ms"] > 0 and dom_name is not None
+        dom_tflops = dom_flops / prof["largest_gemm_ms"] / 1e9 if measured else None
         executed = prof["gemm_flops"] + prof["small_gemm_flops"] + prof["gram_flops"]
-        nt = npad // 128
-        util = profiled_mfma_util(dom_name) if dtype_name == "f64" else None
+        # the committed PMC passes (traffic, matrix-pipe utilisation, shader clock) describe the headline run only
+        pmc_applies = measured and dtype_name == "f64" and args.config == "headline" and (N, d) == (8192, 256)
+        util = profiled_mfma_util(dom_name) if pmc_applies else None
+        traffic = profiled_traffic(dom_name, blocks=None) if pmc_applies else None
+        notes = []
+        if not measured:
+            notes.append(f"T = L^-1 L_V has {t_tiles} 128-tiles at N={N}: no 128-tile launch of its own to time (small-tile instances), "
+                         "achieved / frac are null; see gemm_family and unit_executed_frac")
+        if measured and not pmc_applies:
+            notes.append("traffic / mfma_util / clock are PMC passes of the headline run (N=8192 d=256 f64) and are not copied to other runs")
+        if dtype_name == "mixed":
+            notes.append("mixed precision: T and the other gradient products run on the fp32 MFMA (peak 157.3), the factorisations on the "
+                         "fp64 MFMA (peak 78.6); unit_executed_frac is quoted against the fp32 peak and therefore understates the fp64 half")
         roofline = {
             "bound": "mfma",
-            "kernel": dom_name + " (T = L^-1 L_V, N^3/3 flops, 1 launch/fit, XCD-aware macro-tile schedule; %s)"
-                      % ("v_mfma_f64_16x16x4_f64" if dtype_name == "f64" else "v_mfma_f32_16x16x4_f32"),
-            "note": None if dtype_name != "mixed" else "mixed precision: T and the other gradient products run on the fp32 MFMA "
-                    "(peak 157.3), the factorisations on the fp64 MFMA (peak 78.6); unit_executed_frac is quoted against the "
-                    "fp32 peak and therefore understates the fp64 half",
-            "achieved": round(dom_tflops, 2), "peak": peak, "unit": "TFLOP/s",
-            "frac": round(dom_tflops / peak, 4),
+            "kernel": None if dom_name is None else dom_name + " (T = L^-1 L_V, N^3/3 flops, 1 launch/fit, %s; %s)"
+                      % (dom_how, "v_mfma_f64_16x16x4_f64" if dtype_name == "f64" else "v_mfma_f32_16x16x4_f32"),
+            "note": " | ".join(notes) or None,
+            "achieved": None if dom_tflops is None else round(dom_tflops, 2), "peak": peak, "unit": "TFLOP/s",
+            "frac": None if dom_tflops is None else round(dom_tflops / peak, 4),
             # HBM-side bytes per launch (fetch with the gfx950 correction + write) from the committed PMC passes; the
             # algorithmic operand bytes of the launch are 3 N^2 / 2 x 8 B (two triangular inputs, one triangular output)
-            "traffic": (lambda t: None if t is None else round((t["fetch_corrected"] + t["write"]) * 1e9))(
-                profiled_traffic(dom_name, blocks=None) if dtype_name == "f64" else None),
-            "traffic_detail": profiled_traffic(dom_name, blocks=None) if dtype_name == "f64" else None,
+            "traffic": None if traffic is None else round((traffic["fetch_corrected"] + traffic["write"]) * 1e9),
+            "traffic_detail": traffic,
             "algorithmic_bytes_per_launch": 1.5 * float(npad) ** 2 * (8 if dtype_name == "f64" else 4),
             "mfma_util": util,
-            "launches_per_fit": 1, "avg_launch_ms": round(prof["largest_gemm_ms"], 4),
+            "launches_per_fit": 1 if measured else 0, "avg_launch_ms": round(prof["largest_gemm_ms"], 4) if measured else None,
             "algorithmic_flops_per_launch": dom_flops,
             # `peak` is the nominal-clock figure (2.4 GHz).  The PMC pass shows the shader clock this launch
             # really ran at (the fp64 GEMMs sit near 2.07 GHz in steady state, profiles/r02_clock_probe.txt);
@@ -455,11 +538,10 @@ def main():
             "small_tile_gemm": {"launches_per_fit": prof["small_gemm_launches"], "ms_per_fit": round(prof["small_gemm_ms"], 3),
                                 "tflops": round(prof["small_gemm_flops"] / max(prof["small_gemm_ms"], 1e-9) / 1e9, 2)},
             "gram_ms_per_fit": round(prof["gram_ms"], 3),
-            # SURVEY 8(d)'s algorithmic flop count F_fit = (14/3)N^3 + ... over the unit's time: a speed-up
-            # figure against the textbook formulation (the implementation executes 0.61 of it), NOT a
-            # fraction of peak
+            # SURVEY 8(d)'s algorithmic flop count F_fit = (14/3)N^3 + ... against the flops this formulation executes:
+            # a saving of the FORMULATION (a speed-up factor), never a rate or a fraction of peak
             "unit_algorithmic_flops": F,
-            "unit_algorithmic_tflops_equivalent": round(F / (unit_ms * 1e-3) / 1e12, 2),
+            "formulation_speedup_algorithmic_over_executed_flops": round(F / executed, 3) if executed > 0 else None,
         }
         metric = {"headline": f"GP fits/sec (kernel+chol+solve+grad loglik) at N={N} d={d}",
                   "n4096": f"GP fits/sec (kernel+chol+solve+grad loglik) at N={N} d={d}",
@@ -469,10 +551,12 @@ def main():
                                 + (" (BASELINE configs[2], headline)" if (N, d) == (8192, 256) else " (size override of the headline configuration)"),
                     "n4096": f"N={N} d={d} single cell {dtype_name}, one M-step closure evaluation with 6 gradients (BASELINE configs[1])",
                     "cells64": f"{args.cells} independent cells x N={N} d={d} {dtype_name}, cyclic shard over the ranks, X broadcast once, "
-                               f"{max(1, args.depth)} cells in flight per GPU (BASELINE configs[3])",
+                               + (f"groups of {args.group} cells per call (lock-step factorisations, batched launches)" if args.group > 0
+                                  else f"{max(1, args.depth)} cells in flight per GPU") + " (BASELINE configs[3])",
                     "thetagrid": f"{args.grid_points} theta points x N={N} d={d} {dtype_name} with gradients, cyclic shard over the ranks, "
-                                 f"X, r, m, V broadcast once, V factor reused across points, {max(1, args.depth)} points in flight per GPU "
-                                 f"(BASELINE configs[4])"}[args.config]
+                                 f"X, r, m, V broadcast once, V factor reused across points, "
+                                 + (f"groups of {args.group} points per call (lock-step factorisations, batched launches)" if args.group > 0
+                                    else f"{max(1, args.depth)} points in flight per GPU") + " (BASELINE configs[4])"}[args.config]
         if not want_grad:
             workload += " [forward only]"
         out = {
@@ -487,6 +571,8 @@ def main():
             "loss": res["loss"],
             "roofline": roofline,
         }
+        if accuracy is not None:
+            out["accuracy_vs_fp64"] = accuracy
         if world == 1 and args.config == "headline" and not args.no_in_flight:
             # Beside `value` (evaluations of ONE cell, each waiting for the previous one, as an L-BFGS closure does):
             # what the same GPU delivers when the evaluations are independent (several cells of this size, as in

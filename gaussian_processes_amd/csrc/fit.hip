@@ -856,7 +856,8 @@ static int fit_eval_impl(gpfit_ctx* c, void* stream, const double* theta, const 
                    RP(c->Tbuf), RP(c->Wbuf), RP(c->Zbuf), RP(c->Tmp), RP(c->Abuf), RP(c->Ybuf), RP(c->tvec),
                    RP(c->Mpart), RP(c->Mmat)};
     if (mixed_grad) {
-      // fp64 factorisations (everything the loss depends on), fp32 for the N^3-heavy gradient products:
+      // fp64 factorisations, log-determinants and likelihood; fp32 for the N^3-heavy products T, Q, W and the
+      // pull-back (T's norm, the trace term of the KL, is therefore fp32-derived: 2e-9 on the loss at N = 8192):
       // single-precision copies of the factors and of the O(N^2) / O(N) operands of the adjoint pass.
       // Li -> Kbuf (its input was destroyed by the factorisation), L_V -> Vbuf (likewise; kept while the
       // V factor is reused), cos(delta) -> TmpV, vectors and the d x d metric into spare buffers.

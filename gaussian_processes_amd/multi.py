@@ -111,6 +111,25 @@ def evaluate_units_pipelined(units: Sequence[int], submit_fn: Callable[[int, int
     return out
 
 
+def evaluate_units_grouped(units: Sequence[int], group_fn: Callable[[Sequence[int]], Sequence[Sequence[float]]], device,
+                           group: int) -> torch.Tensor:
+    """Evaluate the local units ``group`` at a time: ``group_fn(us) -> [(loss, g0..g5) for u in us]`` runs one
+    grouped call (``engine.fit_eval_group`` / ``gpfit_fit_eval_batch``: the Cholesky recursions of the whole group
+    in lock step, the products behind them as batched launches).  Units are independent and every
+    unit's numbers are bit-identical to its own evaluation, so the table equals :func:`evaluate_units`'."""
+    if group < 1:
+        raise ValueError("group must be at least 1")
+    out = torch.zeros((len(units), RESULT_WIDTH), dtype=torch.float64, device=device)
+    for g0 in range(0, len(units), group):
+        us = list(units[g0:g0 + group])
+        rows = group_fn(us)
+        if len(rows) != len(us):
+            raise RuntimeError(f"group_fn returned {len(rows)} results for {len(us)} units")
+        for j, row in enumerate(rows):
+            out[g0 + j] = torch.as_tensor(list(row), dtype=torch.float64, device=device)
+    return out
+
+
 def gather_results(local: torch.Tensor, n_units: int) -> torch.Tensor:
     """All ranks receive the [n_units, 7] table in unit order."""
     if not dist.is_initialized() or dist.get_world_size() == 1:
@@ -129,13 +148,16 @@ def gather_results(local: torch.Tensor, n_units: int) -> torch.Tensor:
 
 
 def run_sharded(n_units: int, eval_fn: Callable[[int], Sequence[float]], device, submit_fn=None, collect_fn=None,
-                depth: int = 2, lockstep: bool = False) -> torch.Tensor:
-    """Evaluate all units, sharded cyclically over the ranks; with ``submit_fn`` / ``collect_fn`` the
-    local units are pipelined ``depth`` deep (see :func:`evaluate_units_pipelined`)."""
+                depth: int = 2, lockstep: bool = False, group_fn=None, group: int = 0) -> torch.Tensor:
+    """Evaluate all units, sharded cyclically over the ranks; with ``group_fn`` the local units go ``group`` at a
+    time through one grouped call each (:func:`evaluate_units_grouped`); with ``submit_fn`` / ``collect_fn`` they
+    are pipelined ``depth`` deep (see :func:`evaluate_units_pipelined`)."""
     world = dist.get_world_size() if dist.is_initialized() else 1
     rank = dist.get_rank() if dist.is_initialized() else 0
     mine = partition(n_units, world, rank)
-    if submit_fn is not None and collect_fn is not None:
+    if group_fn is not None:
+        local = evaluate_units_grouped(mine, group_fn, device, max(1, group))
+    elif submit_fn is not None and collect_fn is not None:
         local = evaluate_units_pipelined(mine, submit_fn, collect_fn, device, depth, lockstep)
     else:
         local = evaluate_units(mine, eval_fn, device)

@@ -124,9 +124,10 @@ int gpfit_acosker_diag(gpfit_ctx* ctx, void* stream, double sigma0, const double
  * the result with gpfit_fit_eval_finish.  Independent units (other cells, other theta points) can
  * then be kept in flight on several contexts / streams, so that one unit's latency-bound
  * factorisation overlaps another's GEMMs (multi.py); bit 3 = mixed precision (fp64 entry point only):
- * kernel build, both Cholesky factorisations and every scalar of the loss in fp64, the N^3-heavy
- * products of the gradient (T, Q, W and the pull-back) in fp32 on single-precision copies of the
- * factors -- the hyperparameter-grid configuration (BASELINE configs[4]) at the north star's 1e-5
+ * kernel build, both Cholesky factorisations, both log-determinants, the likelihood and m^T K~^-1 m in fp64, the
+ * N^3-heavy products (T, Q, W and the pull-back) in fp32 on single-precision copies of the factors -- T's norm
+ * included, so the trace term tr(K~^-1 V) of the loss is fp32-derived (measured effect on the loss: 2e-9 relative
+ * over the 512-point lattice at N = 8192, asserted <= 1e-7 in tests/test_gpu_fp32.py) -- the hyperparameter-grid configuration (BASELINE configs[4]) at the north star's 1e-5
  * bar on the log marginal likelihood, which the all-fp32 instance misses on some grid points.
  * lam_m/lam_var/f (device, [N]) may be NULL.  Synchronises `stream` before returning unless bit 2.
  * Returns 0; -2 when theta is outside [lower, upper] (out_host[0] = +inf and gradients

@@ -36,6 +36,9 @@ def worker(rank, world, port, out_dir):
     X0 = torch.from_numpy(syn.stimuli(N, D)) if rank == 0 else None
     X = multi.broadcast_stimuli(X0, (N, D), torch.device("cpu"))
     table = multi.run_sharded(CELLS, lambda u: eval_cell(X, u), torch.device("cpu"))
+    # the grouped driver (two local units per call) shards and gathers the same table
+    grouped = multi.run_sharded(CELLS, None, torch.device("cpu"), group_fn=lambda us: [eval_cell(X, u) for u in us], group=2)
+    assert torch.equal(grouped, table)
     np.save(os.path.join(out_dir, f"table_{rank}.npy"), table.numpy())
     np.save(os.path.join(out_dir, f"x_{rank}.npy"), X.numpy())
     dist.destroy_process_group()
@@ -129,3 +132,24 @@ def test_pipelined_driver_keeps_order_and_depth():
     slots.clear(); max_open[0] = 0
     grp = multi.evaluate_units_pipelined(units, submit, collect, torch.device("cpu"), depth=2, lockstep=True)
     assert torch.equal(grp, out) and max_open[0] == 2 and not open_tickets and slots == [0, 1, 0, 1, 0]
+
+
+def test_grouped_driver_cuts_groups_in_unit_order():
+    """evaluate_units_grouped: groups of `group` consecutive local units, a shorter last group, results in unit
+    order; a group function that loses a unit is an error -- host logic only (GPU: tests/test_gpu_group.py)."""
+    import pytest
+    calls = []
+
+    def group_fn(us):
+        calls.append(list(us))
+        return [[float(u)] + [float(u) * 10 + k for k in range(6)] for u in us]
+
+    units = [3, 5, 8, 13, 21, 34, 55]
+    out = multi.evaluate_units_grouped(units, group_fn, torch.device("cpu"), group=3)
+    assert calls == [[3, 5, 8], [13, 21, 34], [55]]
+    assert out[:, 0].tolist() == [float(u) for u in units] and out[6, 6] == 555.0
+    assert multi.evaluate_units_grouped([], group_fn, torch.device("cpu"), group=4).shape == (0, 7)
+    with pytest.raises(RuntimeError, match="returned 1 results for 2 units"):
+        multi.evaluate_units_grouped([1, 2], lambda us: [[0.0] * 7], torch.device("cpu"), group=2)
+    with pytest.raises(ValueError):
+        multi.evaluate_units_grouped([1], group_fn, torch.device("cpu"), group=0)

@@ -1,6 +1,7 @@
 """fp32 instance of the fused unit of work (hyperparameter-grid configuration, BASELINE
 configs[4]) against the fp64 path on the same inputs.  The reference has no fp32 mode
-(utils.py:31-33), so the fp64 result -- itself pinned to the reference -- is the yardstick.
+(utils.py:31-33), so the fp64 result of this library -- oracle-checked in tests/test_gpu_parity.py -- is the
+yardstick here (a comparison of two instances of the same library, not a pin to the reference).
 
 Stated tolerances: loss 1e-5 relative (the north star's bar), its parts loglik / KL 2e-5 relative,
 gradients 2e-3 of the largest component, posterior vectors 1e-4 relative.  cond(K~) ~ 5e5 at
@@ -70,43 +71,54 @@ def stratified_lattice_points():
 
 
 def test_theta_grid_meets_the_north_star_tolerance():
-    """BASELINE configs[4] at its stated bar (north star: 'log-lik match <= 1e-5 rel'), on 64
-    stratified points of the 512-point lattice incl. all 8 corners, N = 8192, d = 256, V factor reused
-    as the grid driver does.
+    """BASELINE configs[4] at its stated bar (north star: 'log-lik match <= 1e-5 rel') on ALL 512 points of the
+    lattice, N = 8192, d = 256, as the grid driver of bench.py runs it: groups of eight points per call, every
+    context reusing its own copy of the V factor.
 
-    The all-fp32 instance misses the bar on part of the lattice (2.8e-5 at corner 448; measured with
-    scripts/dev_fp32_err.py: rounding K~, V, m to fp32 moves the loss by 1e-8 -- it is the fp32
-    ARITHMETIC of the factorisations, log|K~| off by +0.5 .. +1.7, that does it), so the configuration
-    runs in the mixed mode: kernel build, both Cholesky factorisations and every scalar of the loss in
-    fp64, the N^3-heavy gradient products (T, Q, W, pull-back) in fp32.  Asserted here: mixed mode
-    loss <= 1e-5 (measured ~1e-8), gradients <= 1e-3 of the largest component (the north star states
-    no gradient tolerance); all-fp32 loss <= 5e-5 as a regression bound, not a claim of the bar."""
-    from gaussian_processes_amd.engine import GPFitEngine
+    Yardstick: the fp64 instance of this library on the same lattice (the reference has no reduced-precision mode,
+    utils.py:31-33; the fp64 instance is oracle-checked at this size in tests/test_gpu_parity.py) -- a yardstick,
+    not a second pin.  The all-fp32 instance misses the bar on part of the lattice (2.8e-5 at corner 448; measured
+    with scripts/dev_fp32_err.py: rounding K~, V, m to fp32 moves the loss by 1e-8 -- it is the fp32 ARITHMETIC of
+    the factorisations, log|K~| off by +0.5 .. +1.7, that does it), so the configuration runs in the mixed mode:
+    kernel build, both Cholesky factorisations, both log-determinants, the likelihood and m^T K~^-1 m in fp64; the
+    N^3-heavy products T, Q, W and the pull-back in fp32 -- including T's norm, i.e. the trace term tr(K~^-1 V) of
+    the loss is fp32-derived (its rounding errors average out over N^2 / 2 squares: measured 2e-9 on the loss).
+    Asserted: mixed mode loss <= 1e-5 on every lattice point (the measured maximum is printed and kept two orders
+    below the bar), gradients <= 1e-3 of the largest component (the north star states no gradient tolerance);
+    all-fp32 loss <= 5e-5 on the 64 stratified points, a regression bound and not a claim of the bar."""
+    from gaussian_processes_amd.engine import GPFitEngine, fit_eval_group
     dev = torch.device("cuda:0")
-    N, d = 8192, 256
+    N, d, group = 8192, 256, 8
     grid, X, r, m, V = case(N, d, dev)
-    points, chosen = stratified_lattice_points()
-    assert len(points) == 64 and {0, 7, 56, 63, 448, 455, 504, 511} <= set(chosen)
-    eng = GPFitEngine(N, d)
+    lattice = syn.theta_grid(8)
+    assert len(lattice) == 512
+    engs = [GPFitEngine(N, d) for _ in range(group)]
 
-    def sweep(Xs, rs, ms, Vs, **kw):
+    def sweep(points, Xs, rs, ms, Vs, **kw):
         rows = []
-        for i, th in enumerate(points):
-            o = eng.fit_eval(th, LOWER, UPPER, grid, Xs, rs, ms, Vs, LOGA, LAM0, want_vectors=False, reuse_V=i > 0, **kw)
-            rows.append([o["loss"]] + [o["grad"][k] for k in KEYS])
+        for g0 in range(0, len(points), group):
+            res = fit_eval_group(engs, points[g0:g0 + group], LOWER, UPPER, grid, Xs, rs, ms, Vs, LOGA, LAM0, reuse_V=g0 > 0, **kw)
+            rows += [[o["loss"]] + [o["grad"][k] for k in KEYS] for o in res]
         return np.array(rows)
 
-    ref = sweep(X, r, m, V)
-    mixed = sweep(X, r, m, V, grad_precision="f32")
-    all32 = sweep(*(t.to(torch.float32) for t in (X, r, m, V)))
-    eng.close()
-    for name, got, loss_tol in (("mixed", mixed, 1e-5), ("all-fp32", all32, 5e-5)):
-        loss_dev = np.abs(got[:, 0] - ref[:, 0]) / np.abs(ref[:, 0])
-        grad_dev = np.abs(got[:, 1:] - ref[:, 1:]).max(1) / np.abs(ref[:, 1:]).max(1)
-        print(f"{name} vs fp64 over 64 lattice points: loss max {loss_dev.max():.2e} (point {chosen[int(loss_dev.argmax())]}), "
+    ref = sweep(lattice, X, r, m, V)
+    mixed = sweep(lattice, X, r, m, V, grad_precision="f32")
+    points, chosen = stratified_lattice_points()
+    assert len(points) == 64 and {0, 7, 56, 63, 448, 455, 504, 511} <= set(chosen)
+    all32 = sweep(points, *(t.to(torch.float32) for t in (X, r, m, V)))
+    for e in engs:
+        e.close()
+    assert np.isfinite(ref).all() and len(np.unique(ref[:, 0])) == 512
+    for name, got, base, loss_tol, ids in (("mixed", mixed, ref, 1e-5, list(range(512))), ("all-fp32", all32, ref[chosen], 5e-5, chosen)):
+        loss_dev = np.abs(got[:, 0] - base[:, 0]) / np.abs(base[:, 0])
+        grad_dev = np.abs(got[:, 1:] - base[:, 1:]).max(1) / np.abs(base[:, 1:]).max(1)
+        print(f"{name} vs fp64 over {len(ids)} lattice points: loss max {loss_dev.max():.2e} (point {ids[int(loss_dev.argmax())]}), "
               f"median {np.median(loss_dev):.2e}; grad max {grad_dev.max():.2e}")
-        assert loss_dev.max() <= loss_tol, (name, loss_dev.max(), chosen[int(loss_dev.argmax())])
+        assert loss_dev.max() <= loss_tol, (name, loss_dev.max(), ids[int(loss_dev.argmax())])
         assert grad_dev.max() <= 1e-3, (name, grad_dev.max())
+    # drift guard: the mixed mode sits orders of magnitude below the bar; a regression towards it should be seen
+    mixed_dev = np.abs(mixed[:, 0] - ref[:, 0]) / np.abs(ref[:, 0])
+    assert mixed_dev.max() <= 1e-7, f"mixed-mode loss deviation grew to {mixed_dev.max():.2e} (was 2e-9)"
 
 
 def test_mixed_precision_small_and_ragged():
