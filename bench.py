@@ -201,13 +201,95 @@ def cpu_baseline(n_full, d, n_sample, quick):
     return cores, small, full
 
 
+def projected_report(args, eng, step, res, N, d, ntilde, n_kept, ms_per_step, units_per_s, world, X, Xt, r, Bq, m_b, V_b, th1,
+                     lower, upper, grid, logA, lam0):
+    """JSON line of --config trunc / sparse: the B-projected closure (utils.py:2047-2099) at the reference's default
+    EIGVAL_TOL.  Executed flops and per-family times from HIP events around every GEMM / Gram launch of one more
+    evaluation; roofline of the largest 128-tile launch (K_b = K B or the lift W = (.) B^T, 2 N n_t n flops each)."""
+    eng.set_profile(1)
+    step()
+    prof = eng.get_profile()
+    eng.set_profile(0)
+    peak = FP64_MFMA_PEAK_TFLOPS
+    executed = prof["gemm_flops"] + prof["small_gemm_flops"] + prof["gram_flops"]
+    big_ms, big_fl = prof["largest_gemm_ms"], prof["largest_gemm_flops"]
+    gemm_tflops = prof["gemm_flops"] / (prof["gemm_ms"] * 1e-3) / 1e12 if prof["gemm_ms"] > 0 else 0.0
+    nb = -(-n_kept // 128) * 128
+    # algorithmic flops of the projected closure as the reference writes it, with the gradient in adjoint form (no
+    # dK materialised): kernel build 2 n~^2 d (+ 2 n_t n~ d rectangular), projections K B and B^T (K B):
+    # 2 n_t n~ n + 2 n~ n^2 (+ 2 n~^2 n when the two kernels differ), n x n algebra O(n^3), N x n products with n x n
+    # matrices (a V_b, G_a K^-1, B G: 3 x 2 n_t n^2), the lift W = (.) B^T 2 n_t n~ n (twice when sparse), pull-back 2 n~^2 d
+    nt_ = N
+    alg = (2.0 * ntilde * ntilde * d + 2.0 * nt_ * ntilde * n_kept + 2.0 * ntilde * n_kept ** 2 + 6.0 * nt_ * n_kept ** 2
+           + 2.0 * nt_ * ntilde * n_kept + 2.0 * ntilde * ntilde * d + (14.0 / 3.0) * n_kept ** 3)
+    if ntilde != nt_:
+        alg += 2.0 * nt_ * ntilde * d + 2.0 * ntilde * ntilde * n_kept + 2.0 * ntilde * ntilde * n_kept + 2.0 * nt_ * ntilde * d
+    roofline = {
+        "bound": "mfma",
+        "kernel": "gemm_mfma_kernel<double, ..., 128, 2>: the largest 128-tile launch of the closure (K_b = K B / the lift W = (.) B^T: "
+                  "2 n_t n~ nb flops, nb = n_kept rounded up to 128); v_mfma_f64_16x16x4_f64",
+        "achieved": round(big_fl / big_ms / 1e9, 2) if big_ms > 0 else None, "peak": peak, "unit": "TFLOP/s",
+        "frac": round(big_fl / big_ms / 1e9 / peak, 4) if big_ms > 0 else None,
+        "traffic": None,
+        "avg_launch_ms": round(big_ms, 4) if big_ms > 0 else None, "executed_flops_per_launch": big_fl,
+        "gemm_family": {"what": "all 128-tile GEMM launches, executed flops", "launches_per_fit": prof["gemm_launches"],
+                        "tflops": round(gemm_tflops, 2), "frac": round(gemm_tflops / peak, 4), "ms_per_fit": round(prof["gemm_ms"], 3)},
+        "small_tile_gemm": {"launches_per_fit": prof["small_gemm_launches"], "ms_per_fit": round(prof["small_gemm_ms"], 3),
+                            "tflops": round(prof["small_gemm_flops"] / max(prof["small_gemm_ms"], 1e-9) / 1e9, 2)},
+        "leaf_launches_per_fit": prof["leaf_launches"], "leaf_ms_per_fit": round(prof["leaf_ms"], 3),
+        "gram_ms_per_fit": round(prof["gram_ms"], 3),
+        "flops_executed_per_fit": executed, "unit_ms": round(ms_per_step, 3),
+        "unit_executed_tflops": round(executed / (ms_per_step * 1e-3) / 1e12, 2),
+        "unit_executed_frac": round(executed / (ms_per_step * 1e-3) / 1e12 / peak, 4),
+        "unit_algorithmic_flops": alg,
+        # compulsory HBM traffic of the unit: K~ written and read once, cos(delta) likewise, W written and read once, A_w
+        # written and read once (n~^2 doubles each), the N x nb panels a few times -- against the time at 8 TB/s
+        "hbm_floor_ms": round((8.0 * ntilde * ntilde * 8 + 10.0 * N * nb * 8) / 8e12 * 1e3, 3),
+    }
+    out = {
+        "metric": ("GP fits/sec, B-projected (truncated-rank) M-step closure at the reference's default EIGVAL_TOL, "
+                   f"N={N} d={d}, {n_kept} of {ntilde} eigen-directions kept") if ntilde == N else
+                  (f"GP fits/sec, sparse M-step closure n_t={N} n_tilde={ntilde} d={d} at the reference's default EIGVAL_TOL, "
+                   f"{n_kept} eigen-directions kept"),
+        "value": round(units_per_s, 4), "unit": "fits/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+        "data": "synthetic",
+        "config": {"workload": f"{args.config}: n_t={N} n_tilde={ntilde} d={d} f64, one evaluation of the B-projected closure "
+                               f"(utils.py:2047-2099) with 6 gradients, basis B[{ntilde} x {n_kept}] fixed (as during an M-step)",
+                   "N": N, "d": d, "n_tilde": ntilde, "n_kept": n_kept, "units_per_step": world,
+                   "parallelism": f"independent units over {world} GPU(s), one process per GPU, no data-path collective"},
+        "loss": res["loss"], "roofline": roofline,
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        from oracle import gp_oracle as orc
+        cores = host_cores()
+        torch.set_num_threads(cores)
+        cpu = [t.detach().cpu() for t in (X, Xt, r, Bq, m_b, V_b)]
+        t0 = time.time()
+        loss_ref, grad_ref = orc.mstep_closure_reference(th1, lower, upper, grid, cpu[0], cpu[1], cpu[2], cpu[3], cpu[4], cpu[5], logA, lam0,
+                                                         tol=1e-4)
+        t_ref = time.time() - t0
+        g_ref = np.array([grad_ref[k] for k in syn.THETA_KEYS]); g_gpu = np.array([res["grad"][k] for k in syn.THETA_KEYS])
+        out["cpu_baseline"] = {
+            "value": round(1.0 / t_ref, 6), "unit": "fits/s", "cores": cores, "kind": "port",
+            "sample": f"ONE evaluation of the reference-formulation closure (oracle.mstep_closure_reference, same B, m_b, V_b) at "
+                      f"n_t={N} n_tilde={ntilde} d={d}: {t_ref:.1f} s",
+            "gpu_vs_cpu": round(units_per_s / world * t_ref, 1),
+            "loss_rel_dev_gpu_vs_cpu": abs(res["loss"] - loss_ref) / abs(loss_ref),
+            "grad_dev_rel_to_largest_component": float(np.abs(g_ref - g_gpu).max() / np.abs(g_ref).max()),
+        }
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--config", choices=["headline", "n4096", "cells64", "thetagrid"], default="headline",
-                    help="BASELINE.json configs[2] (default), [1], [3], [4]")
+    ap.add_argument("--config", choices=["headline", "n4096", "cells64", "thetagrid", "trunc", "sparse"], default="headline",
+                    help="BASELINE.json configs[2] (default), [1], [3], [4]; trunc = the headline inputs at the reference's default "
+                         "EIGVAL_TOL (the B-projected closure the reference actually runs there, utils.py:2047-2099); sparse = n_t = N, "
+                         "n_tilde = N / 4 inducing stimuli (utils.py:1677, 1693)")
     ap.add_argument("--n", type=int, default=0, help="override N (headline / n4096 only)")
     ap.add_argument("--d", type=int, default=0, help="override d")
     ap.add_argument("--cells", type=int, default=64)
@@ -249,7 +331,8 @@ def main():
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
 
-    defaults = {"headline": (8192, 256), "n4096": (4096, 128), "cells64": (4096, 128), "thetagrid": (8192, 256)}
+    defaults = {"headline": (8192, 256), "n4096": (4096, 128), "cells64": (4096, 128), "thetagrid": (8192, 256),
+                "trunc": (8192, 256), "sparse": (8192, 256)}
     N, d = defaults[args.config]
     N, d = args.n or N, args.d or d
     grid = syn.grid_for(d)
@@ -283,6 +366,40 @@ def main():
         def step():
             return eng.fit_eval(th1, lower, upper, grid, Xd, rd, md, Vd, logA, lam0, want_grad=want_grad,
                                 want_vectors=False, grad_precision=gprec)
+    elif args.config in ("trunc", "sparse"):
+        # The regime the reference runs at its default tolerance (utils.py:39, 1683): K~ of these inputs keeps ~520 of
+        # its 8192 eigenvalues, every M-step closure is the B-projected one (utils.py:2047-2099) -- here ONE call of
+        # gpfit_fit_eval_projected / gpfit_fit_eval_sparse through the drop-in module, exactly the call varGP makes.
+        from gaussian_processes_amd import utils as gp
+        cell = rank
+        ntilde = N if args.config == "trunc" else N // 4
+        r_np, m_np = syn.cell_inputs(N, cell)
+        r = torch.from_numpy(r_np).to(dev)
+        m = torch.from_numpy(m_np).to(dev)[:ntilde].contiguous()
+        th0t = {k: torch.tensor(v, dtype=torch.float64) for k, v in syn.theta0(cell).items()}
+        th1 = syn.theta_eval(cell)
+        Xt = X if ntilde == N else X[:ntilde].contiguous()
+        C0, mask0 = gp.localker(th0t, upper, lower, grid, grad=False)
+        Xt_m = Xt[:, mask0.to(dev)].contiguous() if not bool(mask0.all()) else Xt
+        K0 = gp.acosker(th0t, Xt_m, Xt_m, C=C0, dC=None, diag=False)
+        _, Bq, Ktb0, _ = gp._stabilised_basis(K0)          # default EIGVAL_TOL: the reference's truncation rule
+        n_kept = int(Bq.shape[1])
+        assert n_kept < ntilde, "these inputs were expected to truncate at the default tolerance"
+        m_b = (Bq.T @ m).contiguous()
+        V_b = (0.5 * Ktb0).contiguous()                     # V = K~(theta0) / 2  ->  V_b = B^T V B
+        del K0
+        f_par = {"logA": torch.tensor(logA, dtype=torch.float64), "lambda0": torch.tensor(lam0, dtype=torch.float64)}
+        lims = (lower, upper)
+        units_per_step, unit_name, scaling = world, "fits", "weak"
+        eng.close()
+        eng = gp.get_engine(N, d, d)                        # the context the drop-in module evaluates on
+
+        def step():
+            if args.config == "trunc":
+                loss, grad = gp._closure_projected(th1, lims, grid, X, r, Bq, m_b, V_b, f_par)
+            else:
+                loss, grad = gp._closure_sparse(th1, lims, grid, X, Xt, r, Bq, m_b, V_b, f_par)
+            return {"loss": loss, "grad": grad}
     elif args.config == "cells64":
         cells = args.cells
         mine = multi.partition(cells, world, rank)
@@ -432,7 +549,14 @@ def main():
                     "bar": 1e-5, "meets_bar": bool(dev_loss.max() <= 1e-5),
                     "against": "fp64 instance of this library on the same lattice (oracle-checked at N=8192: tests/test_gpu_parity.py)"}
 
-    if rank == 0:
+    if rank == 0 and args.config in ("trunc", "sparse"):
+        ms_per_step = elapsed / args.steps * 1e3
+        log(f"timed region done: {ms_per_step:.3f} ms/step")
+        out = projected_report(args, eng, step, res, N, d, ntilde, n_kept, ms_per_step, units_per_step * args.steps / elapsed, world,
+                               X, Xt, r, Bq, m_b, V_b, th1, lower, upper, grid, logA, lam0)
+        print(json.dumps(out), flush=True)
+        eng = None                                          # owned by the drop-in module's pool
+    elif rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         log(f"timed region done: {ms_per_step:.2f} ms/step (host enqueue {eng.last_enqueue_ms():.2f} ms per unit)")
         units_per_s = units_per_step * args.steps / elapsed
@@ -602,7 +726,8 @@ def main():
         print(json.dumps(out), flush=True)
     for e in extra_engines:
         e.close()
-    eng.close()
+    if eng is not None and args.config not in ("trunc", "sparse"):
+        eng.close()
     if dist is not None:
         dist.destroy_process_group()
 

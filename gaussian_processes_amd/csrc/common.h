@@ -129,6 +129,8 @@ struct GramArgsT {
   double s0sq;
   int lower;
   int pad_identity;
+  int mirror;    // lower only: every element below the diagonal is also stored transposed, so Kout holds the full
+                 // symmetric matrix (for callers that multiply with it: no separate symmetrisation pass); Cos stays lower
 };
 using GramArgs = GramArgsT<double>;
 template <typename R> int launch_gram(const GramArgsT<R>& a, hipStream_t s);

@@ -153,6 +153,40 @@ static int gemm(hipStream_t s, int a_kmajor, int b_kmajor, int M, int N, int K, 
                                   reverse, ws, sk_ws, half_occ), plain);
 }
 
+#define GP_TRY(expr)            \
+  do {                          \
+    int _rc = (expr);           \
+    if (_rc != 0) return _rc;   \
+  } while (0)
+
+// C = alpha op(A) op(B) with the k range cut into `splits` slabs: the shapes of the truncated-rank closures whose
+// output has few tiles but a long k (K_b = K~ B: 8192 x 512 x 8192; B^T X: 512 x 512 x 8192) fill the chip with
+// 128-tiles only this way.  The slabs go to `partial` (splits x M x ldc elements) and are added in slab order by
+// one pass (deterministic; C must be the contiguous block [M][ldc]).  splits <= 1: the plain launch.
+template <typename R>
+static int gemm_splitk(hipStream_t s, int a_kmajor, int b_kmajor, int M, int N, int K, double alpha, const R* A, int64_t lda,
+                       const R* B, int64_t ldb, R* C, int64_t ldc, int splits, R* partial, int64_t partial_elems) {
+  static const bool off = getenv("GPFIT_NO_SPLITK") != nullptr;   // tuning knob
+  splits = (int)std::min<int64_t>(splits, partial_elems / std::max<int64_t>(1, (int64_t)M * ldc));   // what the scratch holds
+  if (splits <= 1 || off || partial == nullptr)
+    return gemm<R>(s, a_kmajor, b_kmajor, M, N, K, alpha, A, lda, B, ldb, 0.0, C, ldc, 0, 0, 0);
+  GemmArgsT<R> g = gemm_args<R>(a_kmajor, b_kmajor, M, N, K, alpha, A, lda, B, ldb, 0.0, partial, ldc, 0, 0, 0);
+  g.split_k = splits;
+  g.sC = (int64_t)M * ldc;
+  g.tile = TILE;
+  GP_TRY(run_gemm(s, g));
+  return launch_reduce_slices(partial, (int64_t)M * ldc, splits, C, (int64_t)M * ldc, s);
+}
+// slabs so that a product with few output tiles still launches about one and a half rounds of 128-tile workgroups,
+// each with a k range of at least 256
+static int splitk_for(int M, int N, int K) {
+  const long tiles = (long)((M + TILE - 1) / TILE) * ((N + TILE - 1) / TILE);
+  if (tiles >= 384) return 1;
+  long sp = (768 + tiles - 1) / tiles;
+  sp = std::min<long>(sp, std::max(1, K / 256));
+  return (int)std::max<long>(1, sp);
+}
+
 // tuning knob (bit mask, default all): fused GEMM epilogues -- 1 Q's symmetrisation, 2 T's norm, 4 the H / Z21 update
 // of the two-sided product
 static int fused_epilogues() {
@@ -160,11 +194,6 @@ static int fused_epilogues() {
   return v;
 }
 
-#define GP_TRY(expr)            \
-  do {                          \
-    int _rc = (expr);           \
-    if (_rc != 0) return _rc;   \
-  } while (0)
 
 // ------------------------------------------------------------------ recursive Cholesky (+ inverse)
 template <typename R>
@@ -1220,22 +1249,16 @@ static int fit_eval_projected_impl(gpfit_ctx* c, void* stream, const double* the
   c->lv_valid = false; c->lv32_valid = false;
   c->side_ev_next[0] = c->side_ev_next[1] = 0;
   g_main_sk_ws = c->sk_ws[0];
+  ++g_eval_count;
+  prof_begin(c);
+  struct ProfGuard { gpfit_ctx* c; ~ProfGuard() { prof_end(c); } } prof_guard{c};
   double *Kt = c->Kbuf, *Bp = c->Lbuf, *Kb = c->Libuf, *aV = c->Tbuf, *Ga = c->Zbuf, *GaKi = c->Tmp, *W = c->Wbuf;
   double *S1 = c->Vbuf, *S2 = c->LVbuf, *S3 = c->LiVbuf, *S4 = c->TmpV;   // n x n scratch (leading dimension nb)
   double *mbp = c->mpad, *bvec = c->yv, *gm = c->dq1, *gv = c->dq2;
   GP_HIP(hipMemsetAsync(c->info, 0, 4 * sizeof(int), s));
   GP_HIP(hipMemcpyAsync(c->pix, c->pix_host, (size_t)d * sizeof(int), hipMemcpyHostToDevice, s));
-  // ---- auxiliary stream: log|V_b| (:1326) on its own copy of V_b, in four work matrices the main
-  //      stream does not touch before the join (Abuf, Wbuf, Zbuf, Tmp)
-  GP_HIP(hipEventRecord(c->ev_fork, s));
-  GP_HIP(hipStreamWaitEvent(c->aux, c->ev_fork, 0));
-  GP_TRY(launch_pack_lower(V_b, ldvb, nk, c->Abuf, lb, nb, c->aux));
-  {
-    CholBufsT<R> bv{c->Abuf, c->Wbuf, c->Zbuf, c->Tmp, lb, c->info + 1, 1, c->sk_ws[1]};
-    GP_TRY(potrf_rec<R>(bv, 0, nb, 0, c->aux));
-  }
-  GP_TRY(launch_logdet(c->Wbuf, lb, nk, c->scal + 40, c->aux));
-  GP_HIP(hipEventRecord(c->ev_join, c->aux));
+  // (log|V_b| of :1326: V_b is factored together with K~_b below -- one lock-step recursion on this stream, in
+  // four work matrices nothing else needs before the adjoints: Abuf, Wbuf, Zbuf, Tmp)
   // ---- kernel build (as the full-rank unit): C, X masked, K~ (lower tiles -> mirrored), cos, Kvec, q
   GP_TRY(launch_localker<R>(th, c->pix, d, dp, n_rows, n_cols, c->Cmat, dp, nullptr, s));
   GP_TRY(launch_gather(X, ldx, n, c->pix, d, dp, np, c->Xt, ld, c->Xm, dp, s));
@@ -1246,21 +1269,29 @@ static int fit_eval_projected_impl(gpfit_ctx* c, void* stream, const double* the
     g.XCt = c->XCt; g.Xt = c->Xt; g.q1 = c->q; g.q2 = c->q; g.Kout = Kt; g.Cos = c->Cos;
     g.ld1 = ld; g.ld2 = ld; g.ldk = ld; g.np1 = np; g.np2 = np; g.nv1 = n; g.nv2 = n; g.Kd = dp;
     g.s0sq = s0sq; g.lower = 1; g.pad_identity = 1;
+    g.mirror = 1;   // K~ is multiplied from the left below: stored in full by the tiles themselves
+    ProfScope ps(s, (double)np * (np + TILE) * dp, 2);
     GP_TRY(launch_gram(g, s));
   }
-  GP_TRY(launch_symmetrize(Kt, ld, np, s));
   // ---- projection (utils.py:2047-2049): K_b = K~ B, K~_b = sym(B^T K_b)
   GP_TRY(launch_pad_copy(B, ldb, n, nk, Bp, lb, np, nb, s));
   GP_HIP(hipMemsetAsync(mbp, 0, (size_t)np * sizeof(double), s));
   GP_HIP(hipMemcpyAsync(mbp, m_b, (size_t)nk * sizeof(double), hipMemcpyDeviceToDevice, s));
-  GP_TRY(gemm<R>(s, 0, 1, np, nb, np, 1.0, Kt, ld, Bp, lb, 0.0, Kb, lb, 0, 0, 0));
-  GP_TRY(gemm<R>(s, 1, 1, nb, nb, np, 1.0, Bp, lb, Kb, lb, 0.0, S4, lb, 0, 0, 0));
+  GP_TRY(gemm_splitk<R>(s, 0, 1, np, nb, np, 1.0, Kt, ld, Bp, lb, Kb, lb, splitk_for(np, nb, np), c->Wbuf, (int64_t)c->np_cap * c->np_cap));
+  GP_TRY(gemm_splitk<R>(s, 1, 1, nb, nb, np, 1.0, Bp, lb, Kb, lb, S4, lb, splitk_for(nb, nb, np), c->Wbuf, (int64_t)c->np_cap * c->np_cap));
   GP_TRY(launch_symmetrize_avg(S4, lb, nk, s));                                             // :2048
   GP_TRY(launch_pack_lower(S4, lb, nk, S1, lb, nb, s));
+  GP_TRY(launch_pack_lower(V_b, ldvb, nk, c->Abuf, lb, nb, s));
   {
-    CholBufsT<R> bk{S1, S2, S3, S4, lb, c->info + 0, 0, c->sk_ws[0]};
-    GP_TRY(potrf_rec<R>(bk, 0, nb, 1, s));                                                    // K~_b = L L^T, L^-1  (:2067)
+    // K~_b = L L^T with L^-1 (:2067) and V_b = L_V L_V^T (log|V_b|, :1326) in lock step
+    CholBatchT<R> cb;
+    cb.nb = 2;
+    cb.A[0] = S1; cb.L[0] = S2; cb.Li[0] = S3; cb.Tmp[0] = S4; cb.info[0] = c->info + 0;
+    cb.A[1] = c->Abuf; cb.L[1] = c->Wbuf; cb.Li[1] = c->Zbuf; cb.Tmp[1] = c->Tmp; cb.info[1] = c->info + 1;
+    cb.ld = lb; cb.ws = 0; cb.sk_ws = c->sk_ws[0]; cb.ctx = nullptr; cb.side_min = 0;
+    GP_TRY(potrf_lockstep<R>(cb, 0, nb, 1u, s));
   }
+  GP_TRY(launch_logdet(c->Wbuf, lb, nk, c->scal + 40, s));
   GP_TRY(launch_logdet(S2, lb, nk, c->scal + 3, s));
   // K~_b^-1 = L^-T L^-1 (lower tiles, mirrored)
   GP_TRY(gemm<R>(s, 1, 1, nb, nb, nb, 1.0, S3, lb, S3, lb, 0.0, S1, lb, 1, 2, 1));
@@ -1279,15 +1310,28 @@ static int fit_eval_projected_impl(gpfit_ctx* c, void* stream, const double* the
   GP_TRY(launch_proj_moments(Bp, Kb, aV, lb, nb, mbp, c->Kvec, r, n, A, lambda0, c->lam_m, c->lam_var, c->fvec, gm, gv,
                              c->upart, c->scal + 0, s));
   // ---- adjoints (utils._closure_projected): G_a, G_Kb, G_K~b, W
-  GP_HIP(hipStreamWaitEvent(s, c->ev_join, 0));   // the V_b chain is done with Abuf, Wbuf, Zbuf, Tmp
   GP_TRY(launch_proj_ga(Kb, aV, lb, nb, n, np, gm, gv, mbp, Ga, s));
   GP_TRY(gemm<R>(s, 0, 1, np, nb, nb, 1.0, Ga, lb, Ki, lb, 0.0, GaKi, lb, 0, 0, 0));
-  GP_TRY(gemm<R>(s, 1, 1, nb, nb, np, 1.0, Bp, lb, GaKi, lb, 0.0, c->Abuf, lb, 0, 0, 0));    // P2 = B^T G_a K~_b^-1
+  GP_TRY(gemm_splitk<R>(s, 1, 1, nb, nb, np, 1.0, Bp, lb, GaKi, lb, c->Abuf, lb, splitk_for(nb, nb, np), c->Wbuf, (int64_t)c->np_cap * c->np_cap));   // P2 = B^T G_a K~_b^-1
   GP_TRY(launch_proj_gktb(Ki, S4, c->Abuf, lb, nb, bvec, S3, s));                            // G_K~b
   GP_TRY(launch_proj_gkb(Bp, lb, nb, n, np, gv, GaKi, s));                                   // G_Kb (in place)
   GP_TRY(gemm<R>(s, 0, 1, np, nb, nb, 1.0, Bp, lb, S3, lb, 1.0, GaKi, lb, 0, 0, 0));          // + B G_K~b
-  GP_TRY(gemm<R>(s, 0, 0, np, np, nb, 1.0, GaKi, lb, Bp, lb, 0.0, W, ld, 0, 0, 0));           // W = (.) B^T
-  GP_TRY(launch_symmetrize_avg(W, ld, np, s));
+  // W = sym((.) B^T).  With P = B G_K~b + G_Kb:  1/2 (P B^T + B P^T) = 1/2 [P | B] [B | P]^T -- ONE product with
+  // k = 2 nb that writes the lower tiles only (what the adjoint pass reads): the same flops as the full P B^T, and
+  // neither its upper half nor the averaging pass over N x N exist.  (Falls back to the two steps when 2 nb
+  // columns do not fit the N x N scratch matrices, i.e. when hardly anything was truncated.)
+  if (2 * (int64_t)nb * np <= (int64_t)c->np_cap * c->np_cap) {
+    double *Cat1 = Ga, *Cat2 = aV;   // G_a and a V_b are dead
+    const int64_t l2b = 2 * lb;
+    GP_TRY(launch_pad_copy(GaKi, lb, np, nb, Cat1, l2b, np, nb, s));
+    GP_TRY(launch_pad_copy(Bp, lb, np, nb, Cat1 + nb, l2b, np, nb, s));
+    GP_TRY(launch_pad_copy(Bp, lb, np, nb, Cat2, l2b, np, nb, s));
+    GP_TRY(launch_pad_copy(GaKi, lb, np, nb, Cat2 + nb, l2b, np, nb, s));
+    GP_TRY(gemm<R>(s, 0, 0, np, np, 2 * nb, 0.5, Cat1, l2b, Cat2, l2b, 0.0, W, ld, 1, 0, 0));
+  } else {
+    GP_TRY(gemm<R>(s, 0, 0, np, np, nb, 1.0, GaKi, lb, Bp, lb, 0.0, W, ld, 0, 0, 0));
+    GP_TRY(launch_symmetrize_avg(W, ld, np, s));
+  }
   // ---- pull-back of <W, dK~_p> + <gvec, dKvec_p> to the metric (as gpfit_grad_pullback; gvec = -g_v)
   GP_HIP(hipMemsetAsync(c->bv, 0, (size_t)np * sizeof(R), s));
   GP_HIP(hipMemsetAsync(c->wl, 0, (size_t)np * sizeof(R), s));
@@ -1389,6 +1433,9 @@ static int fit_eval_sparse_impl(gpfit_ctx* c, void* stream, const double* theta,
   c->lv_valid = false; c->lv32_valid = false;
   c->side_ev_next[0] = c->side_ev_next[1] = 0;
   g_main_sk_ws = c->sk_ws[0];
+  ++g_eval_count;
+  prof_begin(c);
+  struct ProfGuard { gpfit_ctx* c; ~ProfGuard() { prof_end(c); } } prof_guard{c};
   double *X1m = c->Xm, *X2m = c->XDt, *Zm = c->XDt2;
   double *Kt = c->Kbuf, *CosT = c->Cos, *Kr = c->Lbuf, *CosR = c->Libuf, *Bp = c->Tbuf, *Kb = c->Zbuf, *am = c->Tmp,
          *aV = c->Abuf;
@@ -1409,29 +1456,43 @@ static int fit_eval_sparse_impl(gpfit_ctx* c, void* stream, const double* theta,
     g.XCt = c->XCt2; g.Xt = c->Xt2; g.q1 = c->q2; g.q2 = c->q2; g.Kout = Kt; g.Cos = CosT;
     g.ld1 = l2; g.ld2 = l2; g.ldk = l2; g.np1 = np2; g.np2 = np2; g.nv1 = n2; g.nv2 = n2; g.Kd = dp;
     g.s0sq = s0sq; g.lower = 1; g.pad_identity = 1;
+    g.mirror = 1;
+    ProfScope ps(s, (double)np2 * (np2 + TILE) * dp, 2);
     GP_TRY(launch_gram(g, s));
   }
-  GP_TRY(launch_symmetrize(Kt, l2, np2, s));
   {
     GramArgsT<R> g{};  // K = acosker(x, xtilde): rectangular, with its cosine matrix
     g.XCt = c->XCt; g.Xt = c->Xt2; g.q1 = c->q; g.q2 = c->q2; g.Kout = Kr; g.Cos = CosR;
     g.ld1 = np1; g.ld2 = l2; g.ldk = l2; g.np1 = np1; g.np2 = np2; g.nv1 = n1; g.nv2 = n2; g.Kd = dp;
     g.s0sq = s0sq; g.lower = 0; g.pad_identity = 0;
     g.ldcos = l2;
+    ProfScope ps(s, 2.0 * np1 * np2 * dp, 2);
     GP_TRY(launch_gram(g, s));
   }
   // ---- projection (:2047-2049, 2067-2068): K_b = K B, K~_b = sym(B^T K~ B), a = K_b K~_b^-1
   GP_TRY(launch_pad_copy(B, ldb, n2, nk, Bp, lb, np2, nb, s));
   GP_HIP(hipMemsetAsync(mbp, 0, (size_t)c->np_cap * sizeof(double), s));
   GP_HIP(hipMemcpyAsync(mbp, m_b, (size_t)nk * sizeof(double), hipMemcpyDeviceToDevice, s));
-  GP_TRY(gemm<R>(s, 0, 1, np1, nb, np2, 1.0, Kr, l2, Bp, lb, 0.0, Kb, lb, 0, 0, 0));
-  GP_TRY(gemm<R>(s, 0, 1, np2, nb, np2, 1.0, Kt, l2, Bp, lb, 0.0, am, lb, 0, 0, 0));          // K~ B (temporary)
-  GP_TRY(gemm<R>(s, 1, 1, nb, nb, np2, 1.0, Bp, lb, am, lb, 0.0, S4, lb, 0, 0, 0));
+  // (skinny products with a long k are cut into k slabs, gemm_splitk; Wbuf is free until the adjoints)
+  GP_TRY(gemm_splitk<R>(s, 0, 1, np1, nb, np2, 1.0, Kr, l2, Bp, lb, Kb, lb, splitk_for(np1, nb, np2), c->Wbuf, (int64_t)c->np_cap * c->np_cap));
+  GP_TRY(gemm_splitk<R>(s, 0, 1, np2, nb, np2, 1.0, Kt, l2, Bp, lb, am, lb, splitk_for(np2, nb, np2), c->Wbuf, (int64_t)c->np_cap * c->np_cap));   // K~ B (temporary)
+  GP_TRY(gemm_splitk<R>(s, 1, 1, nb, nb, np2, 1.0, Bp, lb, am, lb, S4, lb, splitk_for(nb, nb, np2), c->Wbuf, (int64_t)c->np_cap * c->np_cap));
   GP_TRY(launch_symmetrize_avg(S4, lb, nk, s));
   GP_TRY(launch_pack_lower(S4, lb, nk, S1, lb, nb, s));
   {
-    CholBufsT<R> bk{S1, S2, S3, S4, lb, c->info + 0, 0, c->sk_ws[0]};
-    GP_TRY(potrf_rec<R>(bk, 0, nb, 1, s));
+    // K~_b = L L^T with L^-1 and V_b = L_V L_V^T (log|V_b|, :1326) in lock step; the V_b chain lives in four
+    // nb x nb slots of Wbuf, which nothing else needs between the projections above and P2 below
+    double* Vw = c->Wbuf;
+    const int64_t slot = (int64_t)nb * nb;
+    GP_TRY(launch_pack_lower(V_b, ldvb, nk, Vw, lb, nb, s));
+    CholBatchT<R> cb;
+    cb.nb = 2;
+    cb.A[0] = S1; cb.L[0] = S2; cb.Li[0] = S3; cb.Tmp[0] = S4; cb.info[0] = c->info + 0;
+    cb.A[1] = Vw; cb.L[1] = Vw + slot; cb.Li[1] = Vw + 2 * slot; cb.Tmp[1] = Vw + 3 * slot; cb.info[1] = c->info + 1;
+    cb.ld = lb; cb.ws = 0; cb.sk_ws = c->sk_ws[0]; cb.ctx = nullptr; cb.side_min = 0;
+    GP_HIP(hipMemsetAsync(Vw + slot, 0, (size_t)(3 * slot) * sizeof(double), s));   // tiles above the diagonal read as zero
+    GP_TRY(potrf_lockstep<R>(cb, 0, nb, 1u, s));
+    GP_TRY(launch_logdet(Vw + slot, lb, nk, c->scal + 40, s));
   }
   GP_TRY(launch_logdet(S2, lb, nk, c->scal + 3, s));
   GP_TRY(gemm<R>(s, 1, 1, nb, nb, nb, 1.0, S3, lb, S3, lb, 0.0, S1, lb, 1, 2, 1));
@@ -1444,11 +1505,6 @@ static int fit_eval_sparse_impl(gpfit_ctx* c, void* stream, const double* theta,
   GP_TRY(gemm<R>(s, 0, 1, nb, nb, nb, 1.0, S3, lb, Ki, lb, 0.0, S4, lb, 0, 0, 0));            // P1
   GP_TRY(gemm<R>(s, 0, 1, np1, nb, nb, 1.0, Kb, lb, Ki, lb, 0.0, am, lb, 0, 0, 0));           // a
   GP_TRY(gemm<R>(s, 0, 1, np1, nb, nb, 1.0, am, lb, S2, lb, 0.0, aV, lb, 0, 0, 0));           // a V_b
-  {
-    CholBufsT<R> bv{S2, Kt, Kr, c->Wbuf, lb, c->info + 1, 0, c->sk_ws[0]};                    // K~ and K are dead
-    GP_TRY(potrf_rec<R>(bv, 0, nb, 0, s));
-  }
-  GP_TRY(launch_logdet(Kt, lb, nk, c->scal + 40, s));
   GP_TRY(launch_symv_lower(Ki, lb, nb, mbp, bvec, s));
   GP_TRY(launch_dot(mbp, bvec, nb, c->scal + 6, s));
   // ---- moments / likelihood pieces with a = K_b K~_b^-1, per-point adjoints
@@ -1458,7 +1514,8 @@ static int fit_eval_sparse_impl(gpfit_ctx* c, void* stream, const double* theta,
   double* GaKi = Kr;     // [np1][nb]
   GP_TRY(launch_proj_ga(Kb, aV, lb, nb, n1, np1, gm, gv, mbp, Ga, s));
   GP_TRY(gemm<R>(s, 0, 1, np1, nb, nb, 1.0, Ga, lb, Ki, lb, 0.0, GaKi, lb, 0, 0, 0));
-  GP_TRY(gemm<R>(s, 1, 1, nb, nb, np1, 1.0, am, lb, GaKi, lb, 0.0, c->Wbuf, lb, 0, 0, 0));    // P2 = a^T G_a K~_b^-1
+  GP_TRY(gemm_splitk<R>(s, 1, 1, nb, nb, np1, 1.0, am, lb, GaKi, lb, c->Wbuf, lb, splitk_for(nb, nb, np1), c->TmpV + (int64_t)nb * nb,
+                        (int64_t)c->np_cap * c->np_cap - (int64_t)nb * nb));   // P2 = a^T G_a K~_b^-1 (slabs behind P1 in TmpV)
   GP_TRY(launch_proj_gktb(Ki, S4, c->Wbuf, lb, nb, bvec, S3, s));                            // G_K~b
   GP_TRY(launch_proj_gkb(am, lb, nb, n1, np1, gv, GaKi, s));                                 // G_Kb (in place)
   // ---- the two adjoints:  W~ = sym(B G_K~b B^T) [np2 x np2],  W_K = G_Kb B^T [np1 x np2]

@@ -46,14 +46,17 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gram_acos_kernel(GramArgsT<R>
   const R* __restrict__ q2 = p.q2;
   R* __restrict__ Ko = p.Kout;
   R* __restrict__ Co = p.Cos;
+  const bool mirror = p.lower && p.mirror;
 
   for_each_acc<R, TILE>(acc, row0, col0, [&](int row, int col, R g) {
     const int64_t o = (int64_t)row * ldk + col;
     const int64_t oc = (int64_t)row * ldcos + col;
+    if (mirror && row < col) return;   // the strict upper part of a diagonal tile comes from its mirrored lower part
     if (row >= nv1 || col >= nv2) {
       // padding: identity on the diagonal so the padded matrix factorises as [L 0; 0 I]
       if (pad_id) {
         Ko[o] = (row == col) ? (R)1 : (R)0;
+        if (mirror && row > col) Ko[(int64_t)col * ldk + row] = (R)0;
         if (Co) Co[oc] = (R)0;
       }
       return;
@@ -64,6 +67,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gram_acos_kernel(GramArgsT<R>
     const R delta = acos(c);
     const R J = (sqrt((R)1 - c * c) + pi32 * c - delta * c) / pi32;
     Ko[o] = qq * J;
+    if (mirror && row > col) Ko[(int64_t)col * ldk + row] = qq * J;
     if (Co) Co[oc] = c;
   });
 }
