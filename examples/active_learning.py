@@ -1,12 +1,14 @@
 """The closed loop of the reference's one_cell_active_training.ipynb on synthetic stimuli: fit on a start set,
-then repeatedly score every remaining image with the information-gain utility, add the best one as training +
-inducing point, extend the kernel matrices by their latest column and refit from the previous (m, V).
+then repeatedly score every remaining image with the information-gain utility, add the best one to the training
+and inducing sets and refit from the previous posterior.
 
-    python examples/active_learning.py --pool 1200 --start 300 --iterations 5
+    python examples/active_learning.py --pool 1200 --start 300 --iterations 5 [--notebook-step]
 
-The statements are those of tests/active_loop.py (one iteration, checked against the real reference in the GPU
-suite, fixture g9); here they run in a loop with timings.  Works with any module that has the reference's utils
-surface (--utils /path/to/Spatial_GP_repo runs the reference itself on the CPU)."""
+The step between two fits is ``utils.extend_inducing_set``: K~ grown by its latest column and, while every
+eigenvalue is kept, the Cholesky factor of the previous fit extended by one row (gpfit_potrf_append) -- no
+eigendecomposition per added image.  ``--notebook-step`` prepares the refit the notebook's way instead (eigh of the
+grown matrix, :1889-1900) so that the two can be timed against each other; one iteration of the loop is checked
+against the real reference in the GPU suite (fixture g9)."""
 import argparse
 import contextlib
 import copy
@@ -24,22 +26,15 @@ ap.add_argument("--pool", type=int, default=1200, help="images available")
 ap.add_argument("--start", type=int, default=300, help="images of the initial fit")
 ap.add_argument("--iterations", type=int, default=5)
 ap.add_argument("--px", type=int, default=8, help="pixels per side")
-ap.add_argument("--utils", default=None)
+ap.add_argument("--notebook-step", action="store_true", help="eigh of the grown K~ for every added image, as the notebook does")
 args = ap.parse_args()
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-if args.utils:
-    sys.path.insert(0, args.utils)
-    sys.dont_write_bytecode = True
-    os.environ.setdefault("MPLBACKEND", "Agg")
-    with contextlib.redirect_stdout(io.StringIO()):
-        import utils as U
-else:
-    from gaussian_processes_amd import utils as U
+from gaussian_processes_amd import utils as U  # noqa: E402
 from gaussian_processes_amd import synthetic as syn  # noqa: E402
 
-dev = torch.device("cuda") if (not args.utils and torch.cuda.is_available()) else torch.device("cpu")
+dev = torch.device("cuda")
 d = args.px * args.px
 X = torch.from_numpy(syn.stimuli(args.pool, d)).to(dev)
 R = torch.from_numpy(syn.cell_inputs(args.pool, 0)[0]).to(dev)
@@ -87,30 +82,21 @@ for it in range(args.iterations):
         best = remaining[int(u.argmax())]
         sync()
         t_score = time.time() - t0
-        # add it, extend the kernel matrices by their latest column, refit from the previous (m, V)
+        # add it and prepare the refit from the previous posterior
         t0 = time.time()
-        nxt = copy.deepcopy(model)
         in_use = torch.cat((in_use, best[None]))
         n = in_use.shape[0]
-        nxt["xtilde"] = X[in_use]
+        grown = U.extend_inducing_set(model, X[best], route="eigh" if args.notebook_step else None)
+        nxt = {"fit_parameters": dict(model["fit_parameters"]), "hyperparams_tuple": model["hyperparams_tuple"],
+               "f_params": model["f_params"], **grown}
         nxt["fit_parameters"].update({"ntilde": n, "in_use_idx": in_use, "xtilde_idx": in_use, "maxiter": 2})
-        V = B @ model["V_b"] @ B.T
-        V_new = torch.eye(n, dtype=V.dtype, device=V.device)
-        V_new[: n - 1, : n - 1] = 0.5 * (V + V.T)
-        m = B @ model["m_b"]
-        nxt["V"], nxt["m"] = V_new, torch.cat((m, m.mean()[None]))
-        col = U.acosker(th, X[in_use][:, mask], X[in_use][-1, mask][None], C=C, dC=None, diag=False)
-        K_tilde = torch.cat((torch.cat((model["final_kernel"]["K_tilde"], col[:-1]), axis=1), col.T), axis=0)
-        Kvec = U.acosker(th, X[in_use][:, mask], x2=None, C=C, dC=None, diag=True)
-        ev, evec = torch.linalg.eigh(K_tilde, UPLO="L")
-        keep = ev > max(ev.max() * U.EIGVAL_TOL, U.EIGVAL_TOL)
-        Bn = evec[:, keep]
-        nxt["init_kernel"] = {"C": C, "mask": mask, "K_tilde": K_tilde, "K": K_tilde, "Kvec": Kvec, "B": Bn,
-                              "K_tilde_b": torch.diag(ev[keep]), "K_b": K_tilde @ Bn,
-                              "K_tilde_inv_b": torch.diag_embed(1 / ev[keep]), "KKtilde_inv_b": Bn}
+        sync()
+        t_prep = time.time() - t0
+        t0 = time.time()
         model, err = U.varGP(X[in_use], R[in_use], **nxt)
         sync()
         t_fit = time.time() - t0
     assert not err["is_error"], err
     print(f"iteration {it + 1}: scored {remaining.shape[0]} images in {t_score * 1e3:.1f} ms (max utility {float(u.max()):.4f}, image {int(best)}); "
+          f"refit prepared in {t_prep * 1e3:.1f} ms ({nxt['init_kernel']['basis_route']} route), "
           f"refit on {n} images in {t_fit:.2f} s, log marginal {float(model['values_track']['loss_track']['logmarginal'][-1]):.3f}")

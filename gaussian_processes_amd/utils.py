@@ -695,17 +695,22 @@ def _all_eigenvalues_kept(K_tilde):
     Both bounds are rigorous, so ``True`` is a proof that nothing would be truncated; when they are
     inconclusive (or K~ is not numerically positive definite) the caller falls back to
     ``torch.linalg.eigh``.  Returns ``(decided_all_kept, L, Linv)``."""
-    n = K_tilde.shape[0]
     L, Li, _, info = cholesky(K_tilde, want_inverse=True)
     if info != 0:
         return False, None, None
+    return _all_kept_given_factor(K_tilde, Li), L, Li
+
+
+def _all_kept_given_factor(K_tilde, Li):
+    """The two rigorous bounds of ``_all_eigenvalues_kept`` for a K~ whose inverse factor ``Li`` is already known
+    (the closed loop extends the factor by one row per added image, ``cholesky_append``)."""
     lam_max_ub = min(float(torch.diagonal(K_tilde).sum()), float(K_tilde.abs().sum(1).max()))
     ali = Li.abs()
     lam_min_lb = 1.0 / (float(ali.sum(0).max()) * float(ali.sum(1).max()))
     del ali
     if not (math.isfinite(lam_max_ub) and math.isfinite(lam_min_lb)):
-        return False, None, None
-    return lam_min_lb > max(lam_max_ub * EIGVAL_TOL, EIGVAL_TOL), L, Li
+        return False
+    return lam_min_lb > max(lam_max_ub * EIGVAL_TOL, EIGVAL_TOL)
 
 
 def _stabilised_basis(K_tilde, route=None):
@@ -751,8 +756,10 @@ def _stabilised_basis(K_tilde, route=None):
 
     if route is not None:
         if route == "identity":
-            kept, _, Li = _all_eigenvalues_kept(K_tilde)
+            kept, L, Li = _all_eigenvalues_kept(K_tilde)
             out = identity_basis(Li) if kept else None
+            if kept:
+                _BASIS.factor = (L, Li)
         elif route == "eigtop":
             out = truncated_basis()
         elif route == "eigh":
@@ -780,6 +787,7 @@ def _stabilised_basis(K_tilde, route=None):
         if kept:
             hints[key] = "full"
             _BASIS.route = "identity"
+            _BASIS.factor = (L, Li)      # K~ = L L^T, L^-1: kept by varGP for the closed loop (extend_inducing_set)
             return identity_basis(Li)
         if hints.get(key) != "truncated":
             out = truncated_basis()
@@ -1022,6 +1030,77 @@ def _closure_sparse_steps(theta, lims, n_px_side, x, xtilde, r, B, m_b, V_b, f_p
 
 
 @torch.no_grad()
+def extend_inducing_set(fit_model, x_new, route=None):
+    """One image more in the inducing set of a fitted model: everything ``varGP(..., m=, V=, init_kernel=)`` needs
+    to refit from the previous posterior, as the closed loop of ``one_cell_active_training.ipynb`` (:1889-1936)
+    prepares it -- K~ grown "by its latest column", the stabilised basis of the grown matrix, the previous
+    ``(m, V)`` carried over with a unit variance and the mean of ``m`` for the new point.
+
+    Where the notebook eigendecomposes the grown K~ for every added image (:1900), this uses what the previous fit
+    left behind: when its basis was the identity (every eigenvalue kept) and its factor is in
+    ``final_kernel['chol']``, ``L`` and ``L^-1`` are extended by one row in O(n^2) (``cholesky_append``,
+    ``gpfit_potrf_append``) and the same rigorous bounds that proved "all kept" for the old matrix are evaluated
+    for the new one -- no ``eigh``, no refactorisation.  If the bounds no longer prove it (or no factor was kept)
+    the grown matrix goes through ``_stabilised_basis`` like any other.
+
+    Returns ``dict(xtilde=, m=, V=, init_kernel=)``; ``x_new`` is one image (any shape with the model's pixel
+    count).  The caller updates ``fit_parameters['ntilde']`` and passes the training data of its choice.
+    ``route='eigh'`` forces the notebook's own step (eigendecomposition of the grown matrix), for A/B timing."""
+    xt = _cu(fit_model['xtilde'])
+    n, npx = xt.shape
+    row = _cu(x_new).reshape(1, -1)
+    if row.shape[1] != npx:
+        raise ValueError(f"extend_inducing_set: the new image has {row.shape[1]} pixels, the model {npx}")
+    theta = fit_model['hyperparams_tuple'][0]
+    fk = fit_model['final_kernel']
+    C, mask = _cu(fit_model['C']), fit_model['mask'].to(xt.device)
+    K_old, Kvec_old = _cu(fk['K_tilde']), _cu(fk['Kvec'])
+    xt_new = torch.cat((xt, row), 0)
+    xm = xt_new[:, mask].contiguous()
+    col = acosker(theta, xm, xm[n:n + 1].contiguous(), C=C, dC=None, diag=False).reshape(-1)       # latest column, n + 1 entries
+    K_new = torch.empty((n + 1, n + 1), dtype=TORCH_DTYPE, device=xt.device)
+    K_new[:n, :n] = K_old
+    K_new[:n, n] = col[:n]
+    K_new[n, :] = col
+    Kvec_new = torch.cat((Kvec_old, acosker(theta, xm[n:n + 1].contiguous(), x2=None, C=C, dC=None, diag=True).reshape(-1)))
+    # previous posterior in the coordinates of the images, grown by the new point (notebook: identity block, mean of m)
+    B_old = fit_model['B']
+    if _is_identity(B_old) or fit_model.get('basis_route') == 'identity':
+        m_img, V_img = _cu(fit_model['m_b']), _cu(fit_model['V_b'])
+    else:
+        B_old = _cu(B_old)
+        m_img = matmul(B_old, _cu(fit_model['m_b']))
+        V_img = matmul(B_old, matmul(_cu(fit_model['V_b']), B_old, transB=True))
+    V_new = torch.eye(n + 1, dtype=TORCH_DTYPE, device=xt.device)
+    V_new[:n, :n] = (V_img + V_img.T) * 0.5
+    m_new = torch.cat((m_img, m_img.mean().reshape(1)))
+    # basis of the grown matrix
+    forced, route, chol = route, None, None
+    if forced is None and fit_model.get('basis_route') == 'identity' and fk.get('chol') is not None:
+        L = torch.zeros((n + 1, n + 1), dtype=TORCH_DTYPE, device=xt.device)
+        Li = torch.zeros_like(L)
+        L[:n, :n] = _cu(fk['chol']['L'])
+        Li[:n, :n] = _cu(fk['chol']['Linv'])
+        _, info = cholesky_append(L, Li, col)
+        if info == 0 and _all_kept_given_factor(K_new, Li):
+            route, chol = 'identity', {'L': L, 'Linv': Li}
+            B = _mark_identity(torch.eye(n + 1, dtype=TORCH_DTYPE, device=xt.device))
+            Kinv = matmul(Li, Li, transA=True)
+            K_b_, K_inv_b = K_new, (Kinv + Kinv.T) * 0.5
+    if route is None:
+        _BASIS.factor = None
+        _, B, K_b_, K_inv_b = _stabilised_basis(K_new, route=forced)
+        route = _BASIS.route
+        if route == 'identity' and _BASIS.factor is not None:
+            chol = {'L': _BASIS.factor[0], 'Linv': _BASIS.factor[1]}
+        _BASIS.factor = None
+    KB = K_new if route == 'identity' else matmul(K_new, B)
+    init_kernel = {'C': C, 'mask': mask, 'K_tilde': K_new, 'K': K_new, 'Kvec': Kvec_new, 'B': B, 'K_tilde_b': K_b_, 'K_b': KB,
+                   'K_tilde_inv_b': K_inv_b, 'KKtilde_inv_b': B, 'basis_route': route, 'chol': chol}
+    return {'xtilde': xt_new, 'm': m_new, 'V': V_new, 'init_kernel': init_kernel}
+
+
+@torch.no_grad()
 def varGP(x, r, **kwargs):
     """Variational-GP fit (EM) with the reference's call signature and ``fit_model`` schema
     (utils.py:1568-2316): ``varGP(x, r, fit_parameters=..., xtilde=..., hyperparams_tuple=...,
@@ -1095,9 +1174,14 @@ def varGP(x, r, **kwargs):
 
     basis_route = [None]   # route of the basis in force (recorded with every tracked iteration)
 
+    chol_factor = [None]   # (L, L^-1) of the K~ in force when its basis is the identity, else None
+
     def project(Kt, K_):
+        _BASIS.factor = None
         eigvecs_, B_, Ktb, Ktib = _stabilised_basis(Kt)
         basis_route[0] = _BASIS.route
+        chol_factor[0] = _BASIS.factor if _BASIS.route == "identity" else None
+        _BASIS.factor = None
         if _is_identity(B_):
             Kb = K_
             a_ = matmul(Kb, Ktib) if ntilde != nt else B_
@@ -1129,6 +1213,13 @@ def varGP(x, r, **kwargs):
         ik = kwargs['init_kernel']
         C, mask, K_tilde, K, Kvec = _cu(ik['C']), ik['mask'].to(dev), _cu(ik['K_tilde']), _cu(ik['K']), _cu(ik['Kvec'])
         B, K_tilde_b, K_b, K_tilde_inv_b = _cu(ik['B']), _cu(ik['K_tilde_b']), _cu(ik['K_b']), _cu(ik['K_tilde_inv_b'])
+        # an init_kernel prepared by extend_inducing_set says which route built its basis (and brings the factor of
+        # K~ when that basis is the identity); one built the notebook's way (eigh + truncation) carries neither
+        basis_route[0] = ik.get('basis_route', 'eigh')
+        if basis_route[0] == 'identity':
+            B = _mark_identity(B)
+            if ik.get('chol') is not None:
+                chol_factor[0] = (_cu(ik['chol']['L']), _cu(ik['chol']['Linv']))
         KKtilde_inv_b = _cu(ik['KKtilde_inv_b']) if ntilde != nt else B
         x_m = x[:, mask].contiguous()
 
@@ -1348,6 +1439,10 @@ def varGP(x, r, **kwargs):
     if fit_parameters.get('full_eigvecs', False) and (eigvecs is None or eigvecs.shape[1] != eigvecs.shape[0]):
         eigvecs = torch.linalg.eigh(K_tilde, UPLO='L')[1]     # the reference's N x N matrix, on request (utils.py:2241)
     final_kernel = {'C': C, 'mask': mask, 'K_tilde': K_tilde, 'K': K, 'Kvec': Kvec, 'eigvecs': eigvecs}
+    # the factor of the final K~ (identity route only; two more n~ x n~ matrices, so by default only up to the sizes
+    # of the closed-loop experiments): what extend_inducing_set grows by one row instead of refactorising
+    if chol_factor[0] is not None and fit_parameters.get('keep_factor', ntilde <= 4096):
+        final_kernel['chol'] = {'L': chol_factor[0][0], 'Linv': chol_factor[0][1]}
     if not is_simmetric(V_b, 'V_b'):
         print('Final V_b is not simmetric, maximum difference: ', torch.max(torch.abs(V_b - V_b.T)))
         V_b = (V_b + V_b.T) / 2

@@ -951,24 +951,66 @@ def test_active_learning_scoring_step(gp):
     assert int(u.argmax()) == int(u_o.argmax())
 
 
-def test_active_learning_loop_step_matches_reference(gp):
-    """SURVEY 8 f-3 end to end: the statements of one closed-loop iteration of
-    one_cell_active_training.ipynb (tests/active_loop.py) -- fit, utility of all remaining images,
-    best image appended with the kernel matrices updated by their latest column, refit from
-    (m, V, init_kernel) -- run through this module and compared with the same statements run
-    through the real reference (fixture g9): same utilities, same image chosen, same refit."""
-    from active_loop import active_loop_step
+def test_closed_loop_step_matches_reference(gp):
+    """SURVEY 8 f-3 end to end against fixture g9 (one iteration of the closed loop of
+    one_cell_active_training.ipynb run through the real reference by tests/golden/make_golden.py): fit on the
+    start set, information gain of every remaining image, the best one added to the inducing set, refit from the
+    previous posterior.  Written against this module's own API: the utilities come from the batched kernel
+    entry points, and the step between the two fits is ``extend_inducing_set`` -- K~ grown by its latest column
+    and, because every eigenvalue of the start fit was kept, the Cholesky factor of the previous fit extended by one
+    row (``gpfit_potrf_append``) where the notebook runs ``eigh`` on the grown matrix."""
     g = load_golden("g9_active_step.npz")
+    dev = torch.device("cuda")
+    images, spikes = T(g["X"]).to(dev), T(g["R"]).to(dev)
+    n0, pool = int(g["n_start"]), int(g["X"].shape[0])
+    settings = {"ntilde": n0, "maxiter": int(g["maxiter"]), "nEstep": 2, "nMstep": 3, "nFparamstep": 3, "kernfun": "acosker",
+                "cellid": 0, "n_px_side": 8, "display_hyper": False}
+    start_theta = {k: torch.tensor(float(v), dtype=torch.float64, requires_grad=True) for k, v in syn.theta0().items()}
+    link = {"logA": torch.tensor(syn.F_PARAMS["logA"]), "lambda0": torch.tensor(syn.F_PARAMS["lambda0"])}
     with contextlib.redirect_stdout(io.StringIO()), warnings.catch_warnings():
         warnings.simplefilter("ignore")
-        o = active_loop_step(gp, torch.from_numpy(g["X"]), torch.from_numpy(g["R"]), int(g["n_start"]), int(g["maxiter"]),
-                             dev=torch.device("cuda"))
-    assert relerr(o["start_logmarginal"].numpy(), g["start_logmarginal"]) < 1e-6
-    u = o["u2d"].cpu().numpy()
-    assert np.max(np.abs(u - g["u2d"]) / np.abs(g["u2d"])) < 1e-5
-    assert o["i_best"] == int(g["i_best"]) and o["x_idx_best"] == int(g["x_idx_best"])
-    assert relerr(o["K_tilde_new"].cpu().numpy(), g["K_tilde_new"]) < 1e-12
-    assert o["n_kept"] == int(g["n_kept"])
-    assert relerr(o["refit_logmarginal"].numpy(), g["refit_logmarginal"]) < 1e-5
-    assert np.abs(o["refit_theta"].numpy() - g["refit_theta"]).max() < 1e-4
-    assert abs(o["refit_logA"] - float(g["refit_logA"])) < 1e-4
+        first, err = gp.varGP(images[:n0], spikes[:n0], fit_parameters=settings, xtilde=images[:n0],
+                              hyperparams_tuple=(start_theta, LOWER, UPPER), f_params=link)
+    assert not err["is_error"], err
+    assert relerr(first["values_track"]["loss_track"]["logmarginal"].numpy(), g["start_logmarginal"]) < 1e-6
+    # information gain of the images not yet used
+    rest = torch.arange(n0, pool, device=dev)
+    th, px, C, basis = first["hyperparams_tuple"][0], first["mask"].to(dev), first["C"], first["B"]
+    cand = images[rest][:, px].contiguous()
+    k_self = gp.acosker(th, cand, x2=None, C=C, diag=True)
+    k_cross = gp.matmul(gp.acosker(th, cand, images[:n0][:, px].contiguous(), C=C), basis)
+    mean, var = gp.lambda_moments(cand, first["K_tilde_b"], gp.matmul(k_cross, first["K_tilde_inv_b"]), k_self, k_cross, C,
+                                  first["m_b"], first["V_b"], th)
+    gain_A = torch.exp(first["f_params"]["logA"]).to(dev)
+    gain = gp.nd_utility(gain_A ** 2 * var, gain_A * mean + first["f_params"]["lambda0"].to(dev), torch.arange(0, 100, dtype=torch.float64))
+    assert np.max(np.abs(gain.cpu().numpy() - g["u2d"]) / np.abs(g["u2d"])) < 1e-5
+    pick = int(gain.argmax())
+    assert pick == int(g["i_best"]) and int(rest[pick]) == int(g["x_idx_best"])
+    # grow the inducing set by that image and refit from the previous posterior
+    assert first["basis_route"] == "identity" and "chol" in first["final_kernel"]      # nothing was truncated at 48 images
+    grown = gp.extend_inducing_set(first, images[rest[pick]])
+    ik = grown["init_kernel"]
+    assert relerr(ik["K_tilde"].cpu().numpy(), g["K_tilde_new"]) < 1e-12
+    assert ik["basis_route"] == "identity" and ik["B"].shape[1] == int(g["n_kept"])
+    L_ref, Li_ref, _, info = gp.cholesky(ik["K_tilde"], want_inverse=True)            # the appended row against a refactorisation
+    assert info == 0 and relerr(ik["chol"]["L"].cpu().numpy(), L_ref.cpu().numpy()) < 1e-12
+    assert relerr(ik["chol"]["Linv"].cpu().numpy(), Li_ref.cpu().numpy()) < 1e-10
+    used = torch.cat((torch.arange(n0, device=dev), rest[pick:pick + 1]))
+    again = dict(first["fit_parameters"], ntilde=n0 + 1)
+    with contextlib.redirect_stdout(io.StringIO()), warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        second, err = gp.varGP(images[used], spikes[used], fit_parameters=again, xtilde=grown["xtilde"],
+                               hyperparams_tuple=first["hyperparams_tuple"], f_params=first["f_params"], m=grown["m"], V=grown["V"],
+                               init_kernel=ik)
+    assert not err["is_error"], err
+    track = second["values_track"]["loss_track"]["logmarginal"].numpy()
+    dev_track = relerr(track, g["refit_logmarginal"])
+    assert dev_track < 1e-5, f"refit track deviates by {dev_track:.2e}"
+    final = np.array([float(second["hyperparams_tuple"][0][k]) for k in KEYS])
+    assert np.abs(final - g["refit_theta"]).max() < 1e-4 and abs(float(second["f_params"]["logA"]) - float(g["refit_logA"])) < 1e-4
+    # the same step without the stored factor takes the general route and lands on the same refit
+    bare = dict(first)
+    bare["final_kernel"] = {k: v for k, v in first["final_kernel"].items() if k != "chol"}
+    slow = gp.extend_inducing_set(bare, images[rest[pick]])
+    assert slow["init_kernel"]["basis_route"] == "identity" and torch.equal(slow["init_kernel"]["K_tilde"], ik["K_tilde"])
+    assert relerr(slow["init_kernel"]["K_tilde_inv_b"].cpu().numpy(), ik["K_tilde_inv_b"].cpu().numpy()) < 1e-9
