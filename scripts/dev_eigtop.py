@@ -25,3 +25,15 @@ print("n equal:", vals.shape[0] == int(keep.sum()), " eigenvalue rel err:", floa
 P = Bref.T @ vecs
 print("subspace distance ||I - P^T P||:", float((torch.eye(P.shape[1], device=dev, dtype=torch.float64) - P.T @ P).abs().max()),
       " orthonormality:", float((vecs.T @ vecs - torch.eye(vecs.shape[1], device=dev, dtype=torch.float64)).abs().max()))
+# block size / first-sweep sweep (which start needs the fewest products and Rayleigh-Ritz solves?)
+for k0 in (640, 768, 896, 1024):
+    for fs in (8, 12, 16):
+        eigtop.top_eigenpairs(K, 1e-4, gp.matmul, gp.cholesky, k0=k0, first_sweeps=fs)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        o = eigtop.top_eigenpairs(K, 1e-4, gp.matmul, gp.cholesky, k0=k0, first_sweeps=fs)
+        torch.cuda.synchronize(); dt = time.perf_counter() - t0
+        print(f"k0 {k0} first_sweeps {fs}: {dt*1e3:.1f} ms", None if o is None else {k: o[2][k] for k in ("k", "sweeps", "rr", "products", "grown", "n")})
+for k in (512, 768, 1024):
+    S = torch.randn(k, k, device=dev, dtype=torch.float64); S = S + S.T
+    torch.linalg.eigh(S); torch.cuda.synchronize(); t0 = time.perf_counter(); torch.linalg.eigh(S); torch.cuda.synchronize()
+    print(f"torch.linalg.eigh {k} x {k}: {(time.perf_counter()-t0)*1e3:.1f} ms")
