@@ -57,7 +57,8 @@ __device__ __forceinline__ void lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)
 
 constexpr int RL = 128;            // leaf size
 constexpr int RPS = 18;            // LDS row stride of the 16-column panel (elements): conflict-free fragment reads
-constexpr int RL_THREADS = 256;
+constexpr int RL_THREADS = 320;      // four waves that own the tiles + one wave that runs the pivot chains
+constexpr int RL_TILE_THREADS = 256;
 
 __device__ __forceinline__ double rl_readlane(double v, int src_lane) {
   const int lo = __builtin_amdgcn_readlane(__double2loint(v), src_lane);
@@ -200,69 +201,177 @@ __global__ __launch_bounds__(RL_THREADS, 2) void chol_leaf_reg_kernel(LeafBatchT
   using Acc = typename Real<R>::acc_t;
   using V = typename Real<R>::vec_t;
   constexpr int EPC = Real<R>::EPC;
-  __shared__ __attribute__((aligned(16))) R P[RL * RPS];   // the current panel: raw S[., kb], then L[., kb]
-  __shared__ __attribute__((aligned(16))) R Dv[16 * RPS];  // inverse of the 16 x 16 diagonal factor
+  // two panel buffers: while the tile waves update from panel kb, the pivot wave factors column kb + 1 into the other
+  __shared__ __attribute__((aligned(16))) R Pbuf[2][RL * RPS];   // a panel: raw S[., kb], then L[., kb]
+  __shared__ __attribute__((aligned(16))) R Dbuf[2][16 * RPS];   // inverse of its 16 x 16 diagonal factor
+  __shared__ int col_ready[8];                                    // column nx has been written to its panel buffer
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool pivot_wave = wave == 4;
   const int fr = lane & 15;
   int kr[4];  // k index (= C/D row) this lane carries in register r
 #pragma unroll
   for (int r = 0; r < 4; ++r) kr[r] = Real<R>::crow(lane, r);
   // slot t of wave w: t < n1 -> tile (w + t, w), else tile (7 - w + t - n1, 7 - w)
-  const int n1w = 8 - wave;
-  auto slot_iw = [&](int t) { return t < n1w ? wave + t : (7 - wave) + (t - n1w); };
-  auto slot_jw = [&](int t) { return t < n1w ? wave : 7 - wave; };
+  const int tw = pivot_wave ? 0 : wave;   // (the pivot wave owns no tiles; its slots are never touched)
+  const int n1w = 8 - tw;
+  auto slot_iw = [&](int t) { return t < n1w ? tw + t : (7 - tw) + (t - n1w); };
+  auto slot_jw = [&](int t) { return t < n1w ? tw : 7 - tw; };
 
   Acc acc[9];
+  if (!pivot_wave) {
 #pragma unroll
-  for (int t = 0; t < 9; ++t) {
-    const int i = slot_iw(t), j = slot_jw(t);
+    for (int t = 0; t < 9; ++t) {
+      const int i = slot_iw(t), j = slot_jw(t);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) acc[t][r] = A[(int64_t)(16 * i + kr[r]) * lda + 16 * j + fr];
-  }
-  // strict upper tiles of both outputs are zero (the callers read whole 128-blocks)
-  for (int e = tid; e < 28 * 64; e += RL_THREADS) {
-    const int tix = e >> 6, q = e & 63;
-    int ti = 0, rem = tix;  // tix -> (ti, tj) with tj > ti: rows 0..6 hold 7, 6, .. 1 tiles
-    while (rem >= 7 - ti) { rem -= 7 - ti; ++ti; }
-    const int tj = ti + 1 + rem;
-    const int row = 16 * ti + (q >> 2), col = 16 * tj + 4 * (q & 3);
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      L[(int64_t)row * ldl + col + c] = (R)0;
-      Linv[(int64_t)row * ldi + col + c] = (R)0;
+      for (int r = 0; r < 4; ++r) acc[t][r] = A[(int64_t)(16 * i + kr[r]) * lda + 16 * j + fr];
     }
+    // strict upper tiles of both outputs are zero (the callers read whole 128-blocks)
+    for (int e = tid; e < 28 * 64; e += RL_TILE_THREADS) {
+      const int tix = e >> 6, q = e & 63;
+      int ti = 0, rem = tix;  // tix -> (ti, tj) with tj > ti: rows 0..6 hold 7, 6, .. 1 tiles
+      while (rem >= 7 - ti) { rem -= 7 - ti; ++ti; }
+      const int tj = ti + 1 + rem;
+      const int row = 16 * ti + (q >> 2), col = 16 * tj + 4 * (q & 3);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        L[(int64_t)row * ldl + col + c] = (R)0;
+        Linv[(int64_t)row * ldi + col + c] = (R)0;
+      }
+    }
+  } else {
+#pragma unroll
+    for (int t = 0; t < 9; ++t) acc[t] = acc_zero<R>();
+    if (lane < 8) col_ready[lane] = 0;
+    // the pivot chains are the critical path of the kernel and VALU-issue bound; the wave shares its SIMD with a
+    // tile wave whose updates would otherwise take every other issue slot (6.3 k instead of 3.9 k cycles per chain)
+    __builtin_amdgcn_s_setprio(3);
   }
+  lds_barrier();   // the flags are cleared
   LEAF_STAMP(8, 0);
 
+  // Software pipeline over the panels with a dedicated pivot wave.  Iteration kb = -1 .. 7:
+  //     [B1]  (2) tile waves: the rows below panel kb  [B2]
+  //     (3a) the owner of column kb + 1 brings THAT column up to date from panel kb, writes it to the other panel
+  //          buffer and raises col_ready[kb + 1];
+  //     (1)  the pivot wave waits for that flag and factors the 16 x 16 diagonal block (pivots + inverse in one
+  //          sweep) -- a quarter of a panel's time and inherently one wave's work --
+  //     (3b) WHILE the tile waves update the rest of their tiles from panel kb.
+  // Two barriers per panel instead of three; the pivot chain of panel kb + 1 runs beside the updates of panel kb.
   Acc xrow = acc_zero<R>();  // X[kb, j] of the column being walked (its row-kb slot comes before its later rows)
 #pragma unroll 1
-  for (int kb = 0; kb < 8; ++kb) {
+  for (int kb = -1; kb < 8; ++kb) {
     // The tile coordinates of the slots depend on the wave only; left alone, the compiler hoists every
     // LDS offset and store address of every slot out of this loop (100+ VGPRs, spilled to scratch).
     // Re-deriving them from an opaque copy of the wave index each iteration costs one add per access.
-    int wv = wave, lane_o = lane;
+    int wv = tw, lane_o = lane;
     asm volatile("" : "+s"(wv));
     asm volatile("" : "+v"(lane_o));
     const int n1 = 8 - wv;
     auto slot_i = [&](int t) { return t < n1 ? wv + t : (7 - wv) + (t - n1); };
     auto slot_j = [&](int t) { return t < n1 ? wv : 7 - wv; };
-    const int owner = kb < 4 ? kb : 7 - kb;
-    if (wave == owner) {
-      LEAF_STAMP(kb, 0);
-      // ---- (1) column kb -> LDS; factor the diagonal 16 x 16 block and invert the factor
+    const int nx = kb + 1;                               // the column factored ahead in this iteration
+    const int owner_nx = nx < 4 ? nx : 7 - nx;
+    const bool feeds = nx < 8 && !pivot_wave && wave == owner_nx;
+    R* const P = Pbuf[kb & 1];                           // panel kb (kb = -1: unused)
+    R* const Dv = Dbuf[kb & 1];
+    R* const Pn = Pbuf[nx & 1];                          // panel kb + 1
+    R* const Dn = Dbuf[nx & 1];
+
+    // one slot's update from panel kb (phase 3)
+    auto update_slot = [&](Acc& a, int i, int j) {
+      if (j > kb) {
+        // Schur complement  S[i, j] -= L[i, kb] L[j, kb]^T
 #pragma unroll
-      for (int t = 0; t < 9; ++t) {
-        if (slot_j(t) == kb) {
-          const int i = slot_i(t);
+        for (int r = 0; r < 4; ++r)
+          a = Real<R>::mfma(-P[(16 * i + fr) * RPS + kr[r]], P[(16 * j + fr) * RPS + kr[r]], a);
+      } else if (i == kb) {
+        // row kb of the inverse:  X[kb, kb] = Dinv,  X[kb, j] = -Dinv Y[kb, j]
+        Acc nxv;
+        if (j == kb) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) P[(16 * i + kr[r]) * RPS + fr] = acc[t][r];
+          for (int r = 0; r < 4; ++r) nxv[r] = Dv[kr[r] * RPS + fr];
+        } else {
+          nxv = acc_zero<R>();
+#pragma unroll
+          for (int r = 0; r < 4; ++r) nxv = Real<R>::mfma(-Dv[fr * RPS + kr[r]], a[r], nxv);
+        }
+        a = nxv;
+        xrow = nxv;
+      } else if (i > kb) {
+        // running sums of the rows still to come:  Y[i, j] += L[i, kb] X[kb, j]
+        Acc y = (j == kb) ? acc_zero<R>() : a;  // column kb held the raw panel until now
+#pragma unroll
+        for (int r = 0; r < 4; ++r) y = Real<R>::mfma(P[(16 * i + fr) * RPS + kr[r]], xrow[r], y);
+        a = y;
+      }
+    };
+
+    if (kb >= 0) {
+      lds_barrier();   // B1: the diagonal block of panel kb and its inverse are in LDS; everyone is done with panel kb - 1
+      if (pivot_wave) LEAF_STAMP(kb, 4);
+      // ---- (2) rows below: L[i, kb] = S[i, kb] Dinv^T, tiles kb+1 .. 7 dealt to the tile waves
+      if (!pivot_wave) {
+        Acc s0 = acc_zero<R>(), s1 = acc_zero<R>();
+        const int i0 = kb + 1 + wave, i1 = kb + 5 + wave;
+        // both products unconditionally (rows clamped into the panel; results of rows that do not exist are simply
+        // not stored): straight-line code, so the two dependent MFMA chains and their LDS reads interleave
+        const int c0 = i0 < 8 ? i0 : 7, c1 = i1 < 8 ? i1 : 7;
+        {
+          R a0[4], a1[4], dd[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            a0[r] = P[(16 * c0 + fr) * RPS + kr[r]];
+            a1[r] = P[(16 * c1 + fr) * RPS + kr[r]];
+            dd[r] = Dv[fr * RPS + kr[r]];
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            s0 = Real<R>::mfma(a0[r], dd[r], s0);
+            s1 = Real<R>::mfma(a1[r], dd[r], s1);
+          }
+        }
+        if (i0 < 8) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            P[(16 * i0 + kr[r]) * RPS + fr] = s0[r];
+            L[(int64_t)(16 * i0 + kr[r]) * ldl + 16 * kb + fr] = s0[r];
+          }
+        }
+        if (i1 < 8) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            P[(16 * i1 + kr[r]) * RPS + fr] = s1[r];
+            L[(int64_t)(16 * i1 + kr[r]) * ldl + 16 * kb + fr] = s1[r];
+          }
         }
       }
-      lds_fence();
+      lds_barrier();   // B2: L[., kb] is in LDS
+      if (pivot_wave) LEAF_STAMP(kb, 5);
+    }
+    if (feeds) {
+      // ---- (3a) the DIAGONAL tile of column kb + 1 up to date (a Schur update: kb + 1 > kb) and into the other
+      // panel buffer: all the pivot wave needs to start.  The tiles below it follow in (3b).
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        if (slot_j(t) == nx && slot_i(t) == nx) {
+          if (kb >= 0) update_slot(acc[t], nx, nx);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) Pn[(16 * nx + kr[r]) * RPS + fr] = acc[t][r];
+        }
+      }
+      lds_fence();                                   // the tile is in LDS ...
+      if (lane == 0) {
+        __hip_atomic_store(&col_ready[nx], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // ... before its flag
+      }
+    }
+    if (pivot_wave && nx < 8) {
+      // ---- (1) factor the diagonal 16 x 16 block of column nx and invert the factor
+      while (__hip_atomic_load(&col_ready[nx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 0) __builtin_amdgcn_s_sleep(1);
+      LEAF_STAMP(nx, 0);
       R v[16], yh[16];
       {
-        const R* row = P + (16 * kb + (lane & 15)) * RPS;
+        const R* row = Pn + (16 * nx + (lane & 15)) * RPS;
 #pragma unroll
         for (int q = 0; q < 16 / EPC; ++q) {
           const V w = *reinterpret_cast<const V*>(row + EPC * q);
@@ -274,14 +383,14 @@ __global__ __launch_bounds__(RL_THREADS, 2) void chol_leaf_reg_kernel(LeafBatchT
       for (int j = 0; j < 16; ++j) yh[j] = (j == lane_o) ? (R)1 : (R)0;
       int first_bad = 0;
       R myr = (R)0;  // lane k keeps 1 / L_kk
-      LEAF_STAMP(kb, 1);
-      static_for_pivots<R, 0>(v, yh, myr, first_bad, lane, 16 * kb);
-      LEAF_STAMP(kb, 2);
+      LEAF_STAMP(nx, 1);
+      static_for_pivots<R, 0>(v, yh, myr, first_bad, lane, 16 * nx);
+      LEAF_STAMP(nx, 2);
       if (lane == 0 && first_bad != 0) atomicCAS(info, 0, info_base + first_bad);
       if (lane < 16) {
-        R* prow = P + (16 * kb + lane) * RPS;
-        R* drow = Dv + lane * RPS;
-        R* grow = L + (int64_t)(16 * kb + lane) * ldl + 16 * kb;
+        R* prow = Pn + (16 * nx + lane) * RPS;
+        R* drow = Dn + lane * RPS;
+        R* grow = L + (int64_t)(16 * nx + lane) * ldl + 16 * nx;
 #pragma unroll
         for (int q = 0; q < 16 / EPC; ++q) {
           V lv, dv;
@@ -296,74 +405,27 @@ __global__ __launch_bounds__(RL_THREADS, 2) void chol_leaf_reg_kernel(LeafBatchT
           *reinterpret_cast<V*>(grow + EPC * q) = lv;
         }
       }
-      LEAF_STAMP(kb, 3);
+      LEAF_STAMP(nx, 3);
     }
-    lds_barrier();
-    if (wave == owner) LEAF_STAMP(kb, 4);
-    // ---- (2) rows below: L[i, kb] = S[i, kb] Dinv^T, tiles kb+1 .. 7 dealt to the waves
-    {
-      Acc s0 = acc_zero<R>(), s1 = acc_zero<R>();
-      const int i0 = kb + 1 + wave, i1 = kb + 5 + wave;
-      if (i0 < 8) {
+    if (!pivot_wave) {
+      // ---- (3b) every tile wave updates its (other) tiles from panel kb; the rows of column kb + 1 below its
+      // diagonal tile go to the other panel buffer as they become final (the raw panel of the next iteration)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) s0 = Real<R>::mfma(P[(16 * i0 + fr) * RPS + kr[r]], Dv[fr * RPS + kr[r]], s0);
-      }
-      if (i1 < 8) {
+      for (int t = 0; t < 9; ++t) {
+        const int i = slot_i(t), j = slot_j(t);
+        const bool done = feeds && j == nx && i == nx;
+        if (kb >= 0 && !done) update_slot(acc[t], i, j);
+        if (feeds && j == nx && i > nx) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) s1 = Real<R>::mfma(P[(16 * i1 + fr) * RPS + kr[r]], Dv[fr * RPS + kr[r]], s1);
-      }
-      if (i0 < 8) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          P[(16 * i0 + kr[r]) * RPS + fr] = s0[r];
-          L[(int64_t)(16 * i0 + kr[r]) * ldl + 16 * kb + fr] = s0[r];
+          for (int r = 0; r < 4; ++r) Pn[(16 * i + kr[r]) * RPS + fr] = acc[t][r];
         }
       }
-      if (i1 < 8) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          P[(16 * i1 + kr[r]) * RPS + fr] = s1[r];
-          L[(int64_t)(16 * i1 + kr[r]) * ldl + 16 * kb + fr] = s1[r];
-        }
-      }
+      if (wave == 0 && kb >= 0) LEAF_STAMP(kb, 6);
     }
-    lds_barrier();
-    if (wave == owner) LEAF_STAMP(kb, 5);
-    // ---- (3) every wave updates its own tiles from the panel
-#pragma unroll
-    for (int t = 0; t < 9; ++t) {
-      const int i = slot_i(t), j = slot_j(t);
-      if (j > kb) {
-        // Schur complement  S[i, j] -= L[i, kb] L[j, kb]^T
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-          acc[t] = Real<R>::mfma(-P[(16 * i + fr) * RPS + kr[r]], P[(16 * j + fr) * RPS + kr[r]], acc[t]);
-      } else if (i == kb) {
-        // row kb of the inverse:  X[kb, kb] = Dinv,  X[kb, j] = -Dinv Y[kb, j]
-        Acc nx;
-        if (j == kb) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) nx[r] = Dv[kr[r] * RPS + fr];
-        } else {
-          nx = acc_zero<R>();
-#pragma unroll
-          for (int r = 0; r < 4; ++r) nx = Real<R>::mfma(-Dv[fr * RPS + kr[r]], acc[t][r], nx);
-        }
-        acc[t] = nx;
-        xrow = nx;
-      } else if (i > kb) {
-        // running sums of the rows still to come:  Y[i, j] += L[i, kb] X[kb, j]
-        Acc y = (j == kb) ? acc_zero<R>() : acc[t];  // column kb held the raw panel until now
-#pragma unroll
-        for (int r = 0; r < 4; ++r) y = Real<R>::mfma(P[(16 * i + fr) * RPS + kr[r]], xrow[r], y);
-        acc[t] = y;
-      }
-    }
-    lds_barrier();
-    if (wave == owner) LEAF_STAMP(kb, 6);
   }
 
   // all rows of the inverse are final (store addresses derived here, not kept live through the loop)
+  if (pivot_wave) return;
   int wv2 = wave;
   asm volatile("" : "+s"(wv2));
 #pragma unroll

@@ -20,6 +20,20 @@ int main() {
   hipEventRecord(e1, 0); hipDeviceSynchronize();
   float ms; hipEventElapsedTime(&ms, e0, e1);
   printf("back-to-back leaf launches: %.2f us each\n", ms * 10.0);
+  {
+    // correctness of the last launch: L L^T = A, L Li = I (host check, n = 128)
+    std::vector<double> L(n * n), Li(n * n);
+    hipMemcpy(L.data(), dL, n * n * 8, hipMemcpyDeviceToHost); hipMemcpy(Li.data(), dI, n * n * 8, hipMemcpyDeviceToHost);
+    double e1 = 0, e2 = 0, up = 0;
+    for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) {
+      double s1 = 0, s2 = 0;
+      for (int k = 0; k < n; ++k) { s1 += L[i * n + k] * L[j * n + k]; s2 += L[i * n + k] * Li[k * n + j]; }
+      e1 = std::fmax(e1, std::fabs(s1 - A[i * n + j])); e2 = std::fmax(e2, std::fabs(s2 - (i == j ? 1.0 : 0.0)));
+      if (j > i) up = std::fmax(up, std::fmax(std::fabs(L[i * n + j]), std::fabs(Li[i * n + j])));
+    }
+    int h_info = -1; hipMemcpy(&h_info, info, 4, hipMemcpyDeviceToHost);
+    printf("max |L L^T - A| %.3e  max |L Li - I| %.3e  max strict-upper entry %.3e  info %d\n", e1, e2, up, h_info);
+  }
   long long st[72];
   hipMemcpyFromSymbol(st, HIP_SYMBOL(gpfit::g_leaf_stamps), sizeof(st));
   const double t0 = (double)st[64];

@@ -7,7 +7,7 @@ subprocess.check_call([sys.executable, os.path.join(ROOT, "scripts", "make_profi
                        os.path.join(G, f"{tag}_pmcf"), os.path.join(G, f"{tag}_pmcw")], stdout=subprocess.DEVNULL)
 shutil.copy(os.path.join(G, f"{tag}_bench_full.json"), os.path.join(P, f"{tag}_bench.json"))
 shutil.copy(os.path.join(G, f"{tag}_bench_f32.json"), os.path.join(P, f"{tag}_bench_f32.json"))
-for extra in ("bench_mixed.json", "size_sweep.jsonl", "whole_fits.log"):
+for extra in ("bench_mixed.json", "size_sweep.jsonl", "whole_fits.log", "whole_fit_breakdown.json", "active_loop.log"):
     if os.path.exists(os.path.join(G, f"{tag}_{extra}")):
         shutil.copy(os.path.join(G, f"{tag}_{extra}"), os.path.join(P, f"{tag}_{extra}"))
 with open(os.path.join(P, f"{tag}_configs.jsonl"), "w") as o:
