@@ -3,7 +3,7 @@
 #   bash scripts/collect_profiles.sh r02
 # Writes under gpurun_out/<tag>_*; scripts/refresh_profiles.py <tag> condenses them into profiles/.
 tag=${1:-r03}
-part=${2:-all}      # a: headline bench + rocprofv3 passes; b: other configurations, sweeps, whole fits (gpurun calls are capped at 20 min)
+part=${2:-all}      # a: headline bench + rocprofv3 passes; b: other configurations; c: size sweep, whole fits (gpurun calls are capped at 20 min)
 out=gpurun_out
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
 set -x
@@ -32,8 +32,10 @@ python bench.py --config thetagrid --dtype f32 --steps 1 --warmup 0 2>/dev/null 
 python bench.py --config thetagrid --dtype f64 --steps 1 --warmup 0 2>/dev/null >> $out/${tag}_configs.jsonl
 python bench.py --config trunc --steps 20 --warmup 3 2>/dev/null >> $out/${tag}_configs.jsonl
 python bench.py --config sparse --steps 20 --warmup 3 2>/dev/null >> $out/${tag}_configs.jsonl
+fi
+if [ "$part" = "all" ] || [ "$part" = "c" ]; then
 : > $out/${tag}_size_sweep.jsonl
-for n in 1024 2048 4096 6144 8192 12288 16384 32768; do python bench.py --n $n --steps 6 --warmup 2 --no-cpu-baseline 2>/dev/null >> $out/${tag}_size_sweep.jsonl; done
+for n in 1024 2048 4096 6144 8192 12288 16384 32768; do python bench.py --n $n --steps 6 --warmup 2 --no-cpu-baseline --no-in-flight 2>/dev/null >> $out/${tag}_size_sweep.jsonl; done
 : > $out/${tag}_whole_fits.log
 python examples/one_cell_fit.py --n 512 --d 64 >> $out/${tag}_whole_fits.log 2>&1
 python examples/one_cell_fit.py --n 2048 --d 256 >> $out/${tag}_whole_fits.log 2>&1
