@@ -388,7 +388,6 @@ __global__ __launch_bounds__(RL_THREADS, 2) void chol_leaf_reg_kernel(LeafBatchT
       LEAF_STAMP(nx, 2);
       if (lane == 0 && first_bad != 0) atomicCAS(info, 0, info_base + first_bad);
       if (lane < 16) {
-        R* prow = Pn + (16 * nx + lane) * RPS;
         R* drow = Dn + lane * RPS;
         R* grow = L + (int64_t)(16 * nx + lane) * ldl + 16 * nx;
 #pragma unroll
@@ -400,9 +399,8 @@ __global__ __launch_bounds__(RL_THREADS, 2) void chol_leaf_reg_kernel(LeafBatchT
             lv[e] = (j <= lane) ? v[j] : (R)0;
             dv[e] = yh[j] * myr;                       // zero above the diagonal by construction
           }
-          *reinterpret_cast<V*>(prow + EPC * q) = lv;
-          *reinterpret_cast<V*>(drow + EPC * q) = dv;
-          *reinterpret_cast<V*>(grow + EPC * q) = lv;
+          *reinterpret_cast<V*>(drow + EPC * q) = dv;      // (the diagonal rows of L are never read from the panel
+          *reinterpret_cast<V*>(grow + EPC * q) = lv;      //  buffer -- only their inverse is -- and go to memory only)
         }
       }
       LEAF_STAMP(nx, 3);
