@@ -201,10 +201,15 @@ __global__ __launch_bounds__(RL_THREADS, 2) void chol_leaf_reg_kernel(LeafBatchT
   using Acc = typename Real<R>::acc_t;
   using V = typename Real<R>::vec_t;
   constexpr int EPC = Real<R>::EPC;
-  // two panel buffers: while the tile waves update from panel kb, the pivot wave factors column kb + 1 into the other
-  __shared__ __attribute__((aligned(16))) R Pbuf[2][RL * RPS];   // a panel: raw S[., kb], then L[., kb]
-  __shared__ __attribute__((aligned(16))) R Dbuf[2][16 * RPS];   // inverse of its 16 x 16 diagonal factor
-  __shared__ int col_ready[8];                                    // column nx has been written to its panel buffer
+  // LDS (48 KiB).  The raw column and the solved rows need one buffer each: raw column j is read before barrier
+  // B2(j) (by (2) and by the pivot wave) and column j + 1 is written behind it; L[., j] is written before B2(j), read
+  // behind it, and L[., j + 1] is written behind B1(j + 1).  Dinv and the mailbox alternate by panel parity (the
+  // pivot wave writes Dinv of panel j + 1 while the tile waves still read that of panel j).
+  __shared__ __attribute__((aligned(16))) R Rawb[1][RL * RPS];   // raw column j: S[i, j] for i > j, final through panel j - 1
+  __shared__ __attribute__((aligned(16))) R Lpb[1][RL * RPS];    // L[i, j] for i > j (the solved rows of panel j)
+  __shared__ __attribute__((aligned(16))) R Dbuf[2][16 * RPS];   // inverse of the 16 x 16 diagonal factor of panel j
+  __shared__ __attribute__((aligned(16))) R Dgb[2][16 * RPS];    // mailbox: diagonal tile S[j, j], final through panel j - 2
+  __shared__ __attribute__((aligned(16))) R Sx[16 * RPS];        // scratch of the pivot wave (layout changes)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const bool pivot_wave = wave == 4;
@@ -225,6 +230,15 @@ __global__ __launch_bounds__(RL_THREADS, 2) void chol_leaf_reg_kernel(LeafBatchT
       const int i = slot_iw(t), j = slot_jw(t);
 #pragma unroll
       for (int r = 0; r < 4; ++r) acc[t][r] = A[(int64_t)(16 * i + kr[r]) * lda + 16 * j + fr];
+      // prologue of the pipeline: raw column 0 and the diagonal tiles of columns 0 and 1
+      if (j == 0 && i > 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Rawb[0][(16 * i + kr[r]) * RPS + fr] = acc[t][r];
+      }
+      if (i == j && j <= 1) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Dgb[j][kr[r] * RPS + fr] = acc[t][r];
+      }
     }
     // strict upper tiles of both outputs are zero (the callers read whole 128-blocks)
     for (int e = tid; e < 28 * 64; e += RL_TILE_THREADS) {
@@ -242,25 +256,79 @@ __global__ __launch_bounds__(RL_THREADS, 2) void chol_leaf_reg_kernel(LeafBatchT
   } else {
 #pragma unroll
     for (int t = 0; t < 9; ++t) acc[t] = acc_zero<R>();
-    if (lane < 8) col_ready[lane] = 0;
     // the pivot chains are the critical path of the kernel and VALU-issue bound; the wave shares its SIMD with a
     // tile wave whose updates would otherwise take every other issue slot (6.3 k instead of 3.9 k cycles per chain)
     __builtin_amdgcn_s_setprio(3);
   }
-  lds_barrier();   // the flags are cleared
   LEAF_STAMP(8, 0);
 
-  // Software pipeline over the panels with a dedicated pivot wave.  Iteration kb = -1 .. 7:
-  //     [B1]  (2) tile waves: the rows below panel kb  [B2]
-  //     (3a) the owner of column kb + 1 brings THAT column up to date from panel kb, writes it to the other panel
-  //          buffer and raises col_ready[kb + 1];
-  //     (1)  the pivot wave waits for that flag and factors the 16 x 16 diagonal block (pivots + inverse in one
-  //          sweep) -- a quarter of a panel's time and inherently one wave's work --
-  //     (3b) WHILE the tile waves update the rest of their tiles from panel kb.
-  // Two barriers per panel instead of three; the pivot chain of panel kb + 1 runs beside the updates of panel kb.
+  // The pivot wave's part of a panel: factor the 16 x 16 block held row-major in Sx (a row per lane) and invert the
+  // factor by the same sweep; Dinv -> Dbuf[nx & 1], the rows of L -> memory.
+  auto pivot_block = [&](int nx, int lane_o) {
+    R v[16], yh[16];
+    {
+      const R* row = Sx + (lane & 15) * RPS;
+#pragma unroll
+      for (int q = 0; q < 16 / EPC; ++q) {
+        const V w = *reinterpret_cast<const V*>(row + EPC * q);
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) v[EPC * q + e] = (lane < 16) ? w[e] : (R)0;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 16; ++j) yh[j] = (j == lane_o) ? (R)1 : (R)0;
+    int first_bad = 0;
+    R myr = (R)0;  // lane k keeps 1 / L_kk
+    LEAF_STAMP(nx, 1);
+    static_for_pivots<R, 0>(v, yh, myr, first_bad, lane, 16 * nx);
+    LEAF_STAMP(nx, 2);
+    if (lane == 0 && first_bad != 0) atomicCAS(info, 0, info_base + first_bad);
+    if (lane < 16) {
+      R* drow = Dbuf[nx & 1] + lane * RPS;
+      R* grow = L + (int64_t)(16 * nx + lane) * ldl + 16 * nx;
+#pragma unroll
+      for (int q = 0; q < 16 / EPC; ++q) {
+        V lv, dv;
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) {
+          const int j = EPC * q + e;
+          lv[e] = (j <= lane) ? v[j] : (R)0;
+          dv[e] = yh[j] * myr;                       // zero above the diagonal by construction
+        }
+        *reinterpret_cast<V*>(drow + EPC * q) = dv;      // (the diagonal rows of L are never read from LDS --
+        *reinterpret_cast<V*>(grow + EPC * q) = lv;      //  only their inverse is -- and go to memory only)
+      }
+    }
+    LEAF_STAMP(nx, 3);
+  };
+
+  lds_barrier();   // B0: raw column 0 and the first two diagonal tiles are in LDS
+  if (pivot_wave) {
+    // column 0: nothing to update, the diagonal tile goes from the mailbox to the row-per-lane layout
+    int lane_o = lane;
+    asm volatile("" : "+v"(lane_o));
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Sx[kr[r] * RPS + fr] = Dgb[0][kr[r] * RPS + fr];
+    lds_fence();
+    pivot_block(0, lane_o);
+  }
+
+  // Software pipeline over the panels with a dedicated pivot wave, synchronised by workgroup barriers only.
+  // Panel j = 0 .. 7, after barrier B1(j) (Dinv of panel j, raw column j and the diagonal tile of column j + 1,
+  // final through panel j - 1, are in LDS):
+  //   tile waves:  (2) the rows below, L[i, j] = S[i, j] Dinv^T          [B2(j)]
+  //                (3) update their tiles from panel j; the owner of column j + 1 puts its rows below the diagonal
+  //                    into the raw buffer of panel j + 1, the owner of column j + 2 its diagonal tile (final
+  //                    through panel j) into the mailbox                                         [B1(j + 1)]
+  //   pivot wave:  its OWN copy of L[j + 1, j] from the raw column and Dinv (not waiting for (2)), the last Schur
+  //                update of the diagonal tile of column j + 1 from it                          [B2(j)]
+  //                the pivot chain of panel j + 1 -- a quarter of a panel's time, one wave's work -- beside (3)
+  //                                                                                              [B1(j + 1)]
+  // so the chain  Dinv(j) -> L[j + 1, j] -> S[j + 1, j + 1] -> pivots(j + 1)  never leaves the pivot wave and waits
+  // for nobody; two barriers per panel, no flags.
   Acc xrow = acc_zero<R>();  // X[kb, j] of the column being walked (its row-kb slot comes before its later rows)
 #pragma unroll 1
-  for (int kb = -1; kb < 8; ++kb) {
+  for (int kb = 0; kb < 8; ++kb) {
     // The tile coordinates of the slots depend on the wave only; left alone, the compiler hoists every
     // LDS offset and store address of every slot out of this loop (100+ VGPRs, spilled to scratch).
     // Re-deriving them from an opaque copy of the wave index each iteration costs one add per access.
@@ -270,21 +338,104 @@ __global__ __launch_bounds__(RL_THREADS, 2) void chol_leaf_reg_kernel(LeafBatchT
     const int n1 = 8 - wv;
     auto slot_i = [&](int t) { return t < n1 ? wv + t : (7 - wv) + (t - n1); };
     auto slot_j = [&](int t) { return t < n1 ? wv : 7 - wv; };
-    const int nx = kb + 1;                               // the column factored ahead in this iteration
-    const int owner_nx = nx < 4 ? nx : 7 - nx;
-    const bool feeds = nx < 8 && !pivot_wave && wave == owner_nx;
-    R* const P = Pbuf[kb & 1];                           // panel kb (kb = -1: unused)
-    R* const Dv = Dbuf[kb & 1];
-    R* const Pn = Pbuf[nx & 1];                          // panel kb + 1
-    R* const Dn = Dbuf[nx & 1];
+    const int nx = kb + 1;
+    const R* const Raw = Rawb[0];                        // raw column kb
+    R* const P = Lpb[0];                                 // L rows of panel kb
+    const R* const Dv = Dbuf[kb & 1];                    // Dinv of panel kb
+    R* const RawN = Rawb[0];                             // raw column kb + 1 (assembled behind B2(kb))
 
-    // one slot's update from panel kb (phase 3)
-    auto update_slot = [&](Acc& a, int i, int j) {
+    lds_barrier();   // B1(kb)
+    if (pivot_wave) {
+      LEAF_STAMP(kb, 4);
+      if (nx < 8) {
+        // L[nx, kb] = S[nx, kb] Dinv^T  (the same product the tile waves form in (2): same bits)
+        Acc lt = acc_zero<R>();
+#pragma unroll
+        for (int r = 0; r < 4; ++r) lt = Real<R>::mfma(Raw[(16 * nx + fr) * RPS + kr[r]], Dv[fr * RPS + kr[r]], lt);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Sx[kr[r] * RPS + fr] = lt[r];
+        lds_fence();
+        // S[nx, nx] -= L[nx, kb] L[nx, kb]^T  on the mailbox copy (final through panel kb - 1)
+        Acc sd;
+        R f[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          f[r] = Sx[fr * RPS + kr[r]];
+          sd[r] = Dgb[nx & 1][kr[r] * RPS + fr];
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sd = Real<R>::mfma(-f[r], f[r], sd);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Sx[kr[r] * RPS + fr] = sd[r];     // row-major for the row-per-lane pivot sweep
+        lds_fence();
+      }
+      lds_barrier();   // B2(kb)
+      LEAF_STAMP(kb, 5);
+      if (nx < 8) {
+        LEAF_STAMP(nx, 0);
+        pivot_block(nx, lane_o);
+      }
+      continue;
+    }
+
+    // ---- tile waves ----
+    // ---- (2) rows below: L[i, kb] = S[i, kb] Dinv^T, tiles kb+1 .. 7 dealt to the tile waves
+    {
+      Acc s0 = acc_zero<R>(), s1 = acc_zero<R>();
+      const int i0 = kb + 1 + wave, i1 = kb + 5 + wave;
+      // both products unconditionally (rows clamped into the panel; results of rows that do not exist are simply
+      // not stored): straight-line code, so the two dependent MFMA chains and their LDS reads interleave
+      const int c0 = i0 < 8 ? i0 : 7, c1 = i1 < 8 ? i1 : 7;
+      {
+        R a0[4], a1[4], dd[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          a0[r] = Raw[(16 * c0 + fr) * RPS + kr[r]];
+          a1[r] = Raw[(16 * c1 + fr) * RPS + kr[r]];
+          dd[r] = Dv[fr * RPS + kr[r]];
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          s0 = Real<R>::mfma(a0[r], dd[r], s0);
+          s1 = Real<R>::mfma(a1[r], dd[r], s1);
+        }
+      }
+      if (i0 < 8) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          P[(16 * i0 + kr[r]) * RPS + fr] = s0[r];
+          L[(int64_t)(16 * i0 + kr[r]) * ldl + 16 * kb + fr] = s0[r];
+        }
+      }
+      if (i1 < 8) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          P[(16 * i1 + kr[r]) * RPS + fr] = s1[r];
+          L[(int64_t)(16 * i1 + kr[r]) * ldl + 16 * kb + fr] = s1[r];
+        }
+      }
+    }
+    lds_barrier();   // B2(kb): L[., kb] is in LDS
+    // ---- (3) every tile wave updates its tiles from panel kb
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const int i = slot_i(t), j = slot_j(t);
+      Acc& a = acc[t];
       if (j > kb) {
+        if (i == nx && j == nx) continue;   // the pivot wave took this tile over (mailbox of the previous panel)
         // Schur complement  S[i, j] -= L[i, kb] L[j, kb]^T
 #pragma unroll
         for (int r = 0; r < 4; ++r)
           a = Real<R>::mfma(-P[(16 * i + fr) * RPS + kr[r]], P[(16 * j + fr) * RPS + kr[r]], a);
+        if (j == nx) {
+          // final through panel kb: a row of the raw column of the next panel
+#pragma unroll
+          for (int r = 0; r < 4; ++r) RawN[(16 * i + kr[r]) * RPS + fr] = a[r];
+        } else if (i == nx + 1 && j == nx + 1) {
+          // the diagonal tile of column kb + 2, final through panel kb: into the mailbox of the pivot wave
+#pragma unroll
+          for (int r = 0; r < 4; ++r) Dgb[j & 1][kr[r] * RPS + fr] = a[r];
+        }
       } else if (i == kb) {
         // row kb of the inverse:  X[kb, kb] = Dinv,  X[kb, j] = -Dinv Y[kb, j]
         Acc nxv;
@@ -305,121 +456,8 @@ __global__ __launch_bounds__(RL_THREADS, 2) void chol_leaf_reg_kernel(LeafBatchT
         for (int r = 0; r < 4; ++r) y = Real<R>::mfma(P[(16 * i + fr) * RPS + kr[r]], xrow[r], y);
         a = y;
       }
-    };
-
-    if (kb >= 0) {
-      lds_barrier();   // B1: the diagonal block of panel kb and its inverse are in LDS; everyone is done with panel kb - 1
-      if (pivot_wave) LEAF_STAMP(kb, 4);
-      // ---- (2) rows below: L[i, kb] = S[i, kb] Dinv^T, tiles kb+1 .. 7 dealt to the tile waves
-      if (!pivot_wave) {
-        Acc s0 = acc_zero<R>(), s1 = acc_zero<R>();
-        const int i0 = kb + 1 + wave, i1 = kb + 5 + wave;
-        // both products unconditionally (rows clamped into the panel; results of rows that do not exist are simply
-        // not stored): straight-line code, so the two dependent MFMA chains and their LDS reads interleave
-        const int c0 = i0 < 8 ? i0 : 7, c1 = i1 < 8 ? i1 : 7;
-        {
-          R a0[4], a1[4], dd[4];
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            a0[r] = P[(16 * c0 + fr) * RPS + kr[r]];
-            a1[r] = P[(16 * c1 + fr) * RPS + kr[r]];
-            dd[r] = Dv[fr * RPS + kr[r]];
-          }
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            s0 = Real<R>::mfma(a0[r], dd[r], s0);
-            s1 = Real<R>::mfma(a1[r], dd[r], s1);
-          }
-        }
-        if (i0 < 8) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            P[(16 * i0 + kr[r]) * RPS + fr] = s0[r];
-            L[(int64_t)(16 * i0 + kr[r]) * ldl + 16 * kb + fr] = s0[r];
-          }
-        }
-        if (i1 < 8) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            P[(16 * i1 + kr[r]) * RPS + fr] = s1[r];
-            L[(int64_t)(16 * i1 + kr[r]) * ldl + 16 * kb + fr] = s1[r];
-          }
-        }
-      }
-      lds_barrier();   // B2: L[., kb] is in LDS
-      if (pivot_wave) LEAF_STAMP(kb, 5);
     }
-    if (feeds) {
-      // ---- (3a) the DIAGONAL tile of column kb + 1 up to date (a Schur update: kb + 1 > kb) and into the other
-      // panel buffer: all the pivot wave needs to start.  The tiles below it follow in (3b).
-#pragma unroll
-      for (int t = 0; t < 9; ++t) {
-        if (slot_j(t) == nx && slot_i(t) == nx) {
-          if (kb >= 0) update_slot(acc[t], nx, nx);
-#pragma unroll
-          for (int r = 0; r < 4; ++r) Pn[(16 * nx + kr[r]) * RPS + fr] = acc[t][r];
-        }
-      }
-      lds_fence();                                   // the tile is in LDS ...
-      if (lane == 0) {
-        __hip_atomic_store(&col_ready[nx], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // ... before its flag
-      }
-    }
-    if (pivot_wave && nx < 8) {
-      // ---- (1) factor the diagonal 16 x 16 block of column nx and invert the factor
-      while (__hip_atomic_load(&col_ready[nx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 0) __builtin_amdgcn_s_sleep(1);
-      LEAF_STAMP(nx, 0);
-      R v[16], yh[16];
-      {
-        const R* row = Pn + (16 * nx + (lane & 15)) * RPS;
-#pragma unroll
-        for (int q = 0; q < 16 / EPC; ++q) {
-          const V w = *reinterpret_cast<const V*>(row + EPC * q);
-#pragma unroll
-          for (int e = 0; e < EPC; ++e) v[EPC * q + e] = (lane < 16) ? w[e] : (R)0;
-        }
-      }
-#pragma unroll
-      for (int j = 0; j < 16; ++j) yh[j] = (j == lane_o) ? (R)1 : (R)0;
-      int first_bad = 0;
-      R myr = (R)0;  // lane k keeps 1 / L_kk
-      LEAF_STAMP(nx, 1);
-      static_for_pivots<R, 0>(v, yh, myr, first_bad, lane, 16 * nx);
-      LEAF_STAMP(nx, 2);
-      if (lane == 0 && first_bad != 0) atomicCAS(info, 0, info_base + first_bad);
-      if (lane < 16) {
-        R* drow = Dn + lane * RPS;
-        R* grow = L + (int64_t)(16 * nx + lane) * ldl + 16 * nx;
-#pragma unroll
-        for (int q = 0; q < 16 / EPC; ++q) {
-          V lv, dv;
-#pragma unroll
-          for (int e = 0; e < EPC; ++e) {
-            const int j = EPC * q + e;
-            lv[e] = (j <= lane) ? v[j] : (R)0;
-            dv[e] = yh[j] * myr;                       // zero above the diagonal by construction
-          }
-          *reinterpret_cast<V*>(drow + EPC * q) = dv;      // (the diagonal rows of L are never read from the panel
-          *reinterpret_cast<V*>(grow + EPC * q) = lv;      //  buffer -- only their inverse is -- and go to memory only)
-        }
-      }
-      LEAF_STAMP(nx, 3);
-    }
-    if (!pivot_wave) {
-      // ---- (3b) every tile wave updates its (other) tiles from panel kb; the rows of column kb + 1 below its
-      // diagonal tile go to the other panel buffer as they become final (the raw panel of the next iteration)
-#pragma unroll
-      for (int t = 0; t < 9; ++t) {
-        const int i = slot_i(t), j = slot_j(t);
-        const bool done = feeds && j == nx && i == nx;
-        if (kb >= 0 && !done) update_slot(acc[t], i, j);
-        if (feeds && j == nx && i > nx) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) Pn[(16 * i + kr[r]) * RPS + fr] = acc[t][r];
-        }
-      }
-      if (wave == 0 && kb >= 0) LEAF_STAMP(kb, 6);
-    }
+    if (wave == 0) LEAF_STAMP(kb, 6);
   }
 
   // all rows of the inverse are final (store addresses derived here, not kept live through the loop)

@@ -453,12 +453,21 @@ def test_vargp_end_to_end_matches_reference(gp, name, tol_track):
     assert not err["is_error"], err
     assert fit["B"].shape[1] == int(g["n_kept"])
     vt = fit["values_track"]
-    assert relerr(vt["loss_track"]["logmarginal"].numpy(), g["logmarginal"]) < tol_track
-    assert relerr(vt["loss_track"]["KL"].numpy(), g["KL"]) < 10 * tol_track
+    # every bound is asserted with its measured value in the message and printed (pytest -s): drift towards a
+    # bound is visible before it breaks (the truncated / sparse tracks are asserted at the north star's 1e-5)
+    d_track = relerr(vt["loss_track"]["logmarginal"].numpy(), g["logmarginal"])
+    d_kl = relerr(vt["loss_track"]["KL"].numpy(), g["KL"])
     th_final = np.array([float(fit["hyperparams_tuple"][0][k]) for k in KEYS])
-    assert np.abs(th_final - g["theta_final"]).max() < 1e-4
-    assert abs(float(fit["f_params"]["logA"]) - float(g["logA_final"])) < 1e-4
-    assert relerr(R_pred.cpu().numpy(), g["R_pred"]) < 1e-4
+    d_theta = float(np.abs(th_final - g["theta_final"]).max())
+    d_logA = abs(float(fit["f_params"]["logA"]) - float(g["logA_final"]))
+    d_pred = relerr(R_pred.cpu().numpy(), g["R_pred"])
+    print(f"{name}: logmarginal track {d_track:.2e} (bound {tol_track:.0e}), KL track {d_kl:.2e}, theta {d_theta:.2e}, "
+          f"logA {d_logA:.2e}, prediction {d_pred:.2e}")
+    assert d_track < tol_track, f"logmarginal track deviates by {d_track:.2e} (bound {tol_track:.0e})"
+    assert d_kl < 10 * tol_track, f"KL track deviates by {d_kl:.2e}"
+    assert d_theta < 1e-4, f"final theta deviates by {d_theta:.2e}"
+    assert d_logA < 1e-4, f"final logA deviates by {d_logA:.2e}"
+    assert d_pred < 1e-4, f"prediction deviates by {d_pred:.2e}"
     for key in ("fit_parameters", "final_kernel", "err_dict", "xtilde", "hyperparams_tuple", "f_params", "m_b", "V_b",
                 "C", "mask", "K_tilde_b", "K_tilde_inv_b", "K_b", "Kvec", "B", "values_track"):
         assert key in fit
