@@ -36,7 +36,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 from gaussian_processes_amd import multi, synthetic as syn  # noqa: E402
-from gaussian_processes_amd.engine import GPFitEngine, fit_eval_group, fits_flops  # noqa: E402
+from gaussian_processes_amd.engine import (GPFitEngine, fit_eval_group, fit_eval_group_begin, fit_eval_group_finish,  # noqa: E402
+                                           fits_flops)
 
 FP64_MFMA_PEAK_TFLOPS = 78.6  # MI355X dense fp64 matrix peak (AMD datasheet; rocBLAS dgemm reaches 76.7 on-box)
 NOMINAL_GHZ = 2.4                 # MI355X_MICROARCH.md: the clock the peak figures are quoted at
@@ -297,6 +298,9 @@ def main():
     ap.add_argument("--group", type=int, default=None,
                     help="independent units per grouped call (gpfit_fit_eval_batch: their factorisations in lock step, "
                          "batched launches); default 16 for cells64, 8 for thetagrid; 0 = the pipelined driver of --depth")
+    ap.add_argument("--sets", type=int, default=2,
+                    help="sets of --group engines for the grouped configurations: with 2 the next group is enqueued before the "
+                         "previous one is collected (the host's share of a group runs beside the GPU's); 1 = one group at a time")
     ap.add_argument("--depth", type=int, default=None,
                     help="with --group 0: independent units kept in flight per GPU on as many contexts (default 3)")
     ap.add_argument("--cpu-sample-n", type=int, default=4096)
@@ -408,16 +412,24 @@ def main():
             rc, mc = syn.cell_inputs(N, c)
             inputs[c] = (torch.from_numpy(rc).to(dev), torch.from_numpy(mc).to(dev), build_V(X, grid, syn.theta0(c), dev),
                          syn.theta_eval(c))
-        n_eng = max(1, args.group) if args.group > 0 else max(1, args.depth)
+        n_eng = max(1, args.group) * max(1, args.sets) if args.group > 0 else max(1, args.depth)
         engs = [eng] + [GPFitEngine(N, d, device=local_rank) for _ in range(n_eng - 1)]
         extra_engines = engs[1:]
         streams = [torch.cuda.Stream(device=dev) for _ in engs]
 
-        def group_cells(cs):
-            sel = [inputs[c] for c in cs]
-            res = fit_eval_group(engs, [t[3] for t in sel], lower, upper, grid, X, [t[0] for t in sel], [t[1] for t in sel],
-                                 [t[2] for t in sel], logA, lam0, want_grad=want_grad)
+        def rows_of(res):
             return [[o["loss"]] + [o["grad"][k] for k in syn.THETA_KEYS] for o in res]
+
+        def begin_cells(cs, slot):   # one set of engines per slot: the next group is enqueued before this one is collected
+            sel = [inputs[c] for c in cs]
+            return fit_eval_group_begin(engs[slot * args.group:(slot + 1) * args.group], [t[3] for t in sel], lower, upper, grid, X,
+                                        [t[0] for t in sel], [t[1] for t in sel], [t[2] for t in sel], logA, lam0, want_grad=want_grad)
+
+        def finish_cells(handle, slot):
+            return rows_of(fit_eval_group_finish(handle))
+
+        def group_cells(cs):
+            return finish_cells(begin_cells(cs, 0), 0)
 
         def submit(c, slot):
             rc, mc, Vc, thc = inputs[c]
@@ -434,7 +446,8 @@ def main():
 
         def step():
             if args.group > 0:
-                table[0] = multi.run_sharded(cells, None, dev, group_fn=group_cells, group=args.group)
+                table[0] = multi.run_sharded(cells, None, dev, group_fn=group_cells, group=args.group, begin_fn=begin_cells,
+                                             finish_fn=finish_cells, sets=args.sets)
             else:
                 table[0] = multi.run_sharded(cells, None, dev, submit_fn=submit, collect_fn=collect, depth=len(engs))
             return {"loss": float(table[0][0, 0])}
@@ -464,19 +477,28 @@ def main():
         # point's latency-bound Cholesky chain runs beside another's large gradient products (each context
         # factors V once and then reuses its own copy of the factor)
         tdepth = max(1, args.depth)
-        n_eng = max(1, args.group) if args.group > 0 else tdepth
+        n_eng = max(1, args.group) * max(1, args.sets) if args.group > 0 else tdepth
         engs = [eng] + [GPFitEngine(N, d, device=local_rank) for _ in range(n_eng - 1)]
         extra_engines = engs[1:]
         streams = [torch.cuda.Stream(device=dev) for _ in engs]
         fresh = [True] * len(engs)
-        group_calls = [0]
+        set_calls = [0] * max(1, args.sets)
+
+        def rows_of(res):
+            return [[o["loss"]] + [o["grad"][k] for k in syn.THETA_KEYS] for o in res]
+
+        def begin_points(us, slot):
+            # every context factors V in its first group and reuses its own copy of the factor afterwards
+            h = fit_eval_group_begin(engs[slot * args.group:(slot + 1) * args.group], [points[u] for u in us], lower, upper, grid, Xd,
+                                     rd, md, Vd, logA, lam0, want_grad=want_grad, reuse_V=set_calls[slot] > 0, grad_precision=gprec)
+            set_calls[slot] += 1
+            return h
+
+        def finish_points(handle, slot):
+            return rows_of(fit_eval_group_finish(handle))
 
         def group_points(us):
-            # every context factors V in its first group and reuses its own copy of the factor afterwards
-            res = fit_eval_group(engs, [points[u] for u in us], lower, upper, grid, Xd, rd, md, Vd, logA, lam0, want_grad=want_grad,
-                                 reuse_V=group_calls[0] > 0, grad_precision=gprec)
-            group_calls[0] += 1
-            return [[o["loss"]] + [o["grad"][k] for k in syn.THETA_KEYS] for o in res]
+            return finish_points(begin_points(us, 0), 0)
 
         def eval_point(u):
             o = eng.fit_eval(points[u], lower, upper, grid, Xd, rd, md, Vd, logA, lam0, want_grad=want_grad,
@@ -497,7 +519,8 @@ def main():
 
         def step():
             if args.group > 0:
-                t = multi.run_sharded(npts, None, dev, group_fn=group_points, group=args.group)
+                t = multi.run_sharded(npts, None, dev, group_fn=group_points, group=args.group, begin_fn=begin_points,
+                                      finish_fn=finish_points, sets=args.sets)
             elif tdepth == 1:
                 t = multi.run_sharded(npts, eval_point, dev)
             else:
@@ -513,8 +536,8 @@ def main():
             calls = [0]
 
             def group64(us):
-                res = fit_eval_group(engs, [points[u] for u in us], lower, upper, grid, X, r64, m64, V64, logA, lam0, want_grad=want_grad,
-                                     reuse_V=calls[0] > 0)
+                res = fit_eval_group(engs[:len(us)], [points[u] for u in us], lower, upper, grid, X, r64, m64, V64, logA, lam0,
+                                     want_grad=want_grad, reuse_V=calls[0] > 0)
                 calls[0] += 1
                 return [[o["loss"]] + [o["grad"][k] for k in syn.THETA_KEYS] for o in res]
             g = args.group if args.group > 0 else min(8, len(engs))
@@ -675,11 +698,11 @@ def main():
                                 + (" (BASELINE configs[2], headline)" if (N, d) == (8192, 256) else " (size override of the headline configuration)"),
                     "n4096": f"N={N} d={d} single cell {dtype_name}, one M-step closure evaluation with 6 gradients (BASELINE configs[1])",
                     "cells64": f"{args.cells} independent cells x N={N} d={d} {dtype_name}, cyclic shard over the ranks, X broadcast once, "
-                               + (f"groups of {args.group} cells per call (lock-step factorisations, batched launches)" if args.group > 0
+                               + (f"groups of {args.group} cells per call (lock-step factorisations, batched launches), {args.sets} set(s) of engines" if args.group > 0
                                   else f"{max(1, args.depth)} cells in flight per GPU") + " (BASELINE configs[3])",
                     "thetagrid": f"{args.grid_points} theta points x N={N} d={d} {dtype_name} with gradients, cyclic shard over the ranks, "
                                  f"X, r, m, V broadcast once, V factor reused across points, "
-                                 + (f"groups of {args.group} points per call (lock-step factorisations, batched launches)" if args.group > 0
+                                 + (f"groups of {args.group} points per call (lock-step factorisations, batched launches), {args.sets} set(s) of engines" if args.group > 0
                                     else f"{max(1, args.depth)} points in flight per GPU") + " (BASELINE configs[4])"}[args.config]
         if not want_grad:
             workload += " [forward only]"

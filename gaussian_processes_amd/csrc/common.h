@@ -12,6 +12,7 @@ namespace gpfit {
 constexpr double PI32 = 3.1415927410125732;
 
 constexpr int TILE = 128;  // GEMM block tile (M and N) and Cholesky leaf size
+constexpr int TRMV_ROWS = 128;  // rows per block of the transposed triangular matrix-vector product (partials: np / TRMV_ROWS slices)
 constexpr int KTILE = 16;  // fp64 GEMM K step staged through LDS (fp32: 32, see ktile_of)
 
 void set_error(const std::string& msg);

@@ -50,8 +50,11 @@ struct gpfit_ctx {
   bool phase_valid = false;
   double last_enqueue_ms = 0.0;  // host time spent enqueuing the last fit_eval
   // evaluation enqueued but not yet collected (gpfit_fit_eval with the async flag / _finish)
+  // done: recorded behind the result copies of a group (gpfit_fit_eval_batch), so that collecting a unit waits for
+  // ITS group only and a second group can already run on the same stream (the single-unit call syncs the stream)
   struct Pending { bool active = false; hipStream_t stream = nullptr; double A = 0, lambda0 = 0, sigma0 = 0;
-                   int n = 0, np = 0, d = 0, want_grad = 0, elem_bytes = 8; } pend;
+                   int n = 0, np = 0, d = 0, want_grad = 0, elem_bytes = 8; hipEvent_t done = nullptr;
+                   bool use_done = false; } pend;
 
   // cached state of the last upload / evaluation (used by estep / predict entry points)
   int cur_n = 0, cur_np = 0, cur_d = 0, cur_dp = 0;

@@ -118,19 +118,32 @@ int launch_gather(const R* X, int64_t ldx, int n, const int* pix, int d, int dp,
 }
 
 // ------------------------------------------------------------------ q / Kvec
+// One block = 32 samples x 8 slices of the pixel range: a thread sums every eighth pixel of its sample (coalesced over
+// the samples), the eight partial sums meet in LDS in a fixed order.  (One thread per sample walked all dp pixels
+// with one load in flight: 37 us at N = 4096, 67 us at N = 8192 -- latency, not bandwidth.)
 template <typename R>
-__global__ void qvec_kernel(const R* __restrict__ Xt, const R* __restrict__ XCt, int64_t ld, int dp, int n, int np,
-                            double s0sq, R* __restrict__ Kvec, R* __restrict__ q) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= np) return;
+__global__ __launch_bounds__(256) void qvec_kernel(const R* __restrict__ Xt, const R* __restrict__ XCt, int64_t ld, int dp,
+                                                   int n, int np, double s0sq, R* __restrict__ Kvec, R* __restrict__ q) {
+  __shared__ double part[8][33];
+  const int li = threadIdx.x & 31, sl = threadIdx.x >> 5;
+  const int i = blockIdx.x * 32 + li;
+  double h = 0.0;
+  if (i < n) {
+#pragma unroll 4
+    for (int k = sl; k < dp; k += 8) h += (double)Xt[(int64_t)k * ld + i] * (double)XCt[(int64_t)k * ld + i];
+  }
+  part[sl][li] = h;
+  __syncthreads();
+  if (sl != 0 || i >= np) return;
   if (i >= n) {
     Kvec[i] = (R)1;
     q[i] = (R)1;
     return;
   }
-  double h = 0.0;
-  for (int k = 0; k < dp; ++k) h += (double)Xt[(int64_t)k * ld + i] * (double)XCt[(int64_t)k * ld + i];
-  const double kv = h + s0sq;  // utils.py:1029
+  double t = part[0][li];
+#pragma unroll
+  for (int z = 1; z < 8; ++z) t += part[z][li];
+  const double kv = t + s0sq;  // utils.py:1029
   Kvec[i] = (R)kv;
   q[i] = (R)sqrt(kv);          // utils.py:978
 }
@@ -138,18 +151,55 @@ __global__ void qvec_kernel(const R* __restrict__ Xt, const R* __restrict__ XCt,
 template <typename R>
 int launch_qvec(const R* Xt, const R* XCt, int64_t ld, int dp, int n, int np, double s0sq, R* Kvec, R* q,
                 hipStream_t s) {
-  hipLaunchKernelGGL(qvec_kernel<R>, dim3((np + 255) / 256), dim3(256), 0, s, Xt, XCt, ld, dp, n, np, s0sq, Kvec, q);
+  hipLaunchKernelGGL(qvec_kernel<R>, dim3((np + 31) / 32), dim3(256), 0, s, Xt, XCt, ld, dp, n, np, s0sq, Kvec, q);
+  GP_HIP(hipGetLastError());
+  return 0;
+}
+
+// ------------------------------------------------------------------ group housekeeping (kernels.h)
+template <typename R>
+__global__ __launch_bounds__(256) void group_prepare_kernel(GroupPrepT<R> g) {
+  const int u = blockIdx.y;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < g.np) g.mpad[u][i] = (i < g.n) ? g.m[u][i] : (R)0;
+  if (blockIdx.x == 0) {
+    for (int k = threadIdx.x; k < g.d[u]; k += 256) g.pix[u][k] = g.pix_host[u][k];
+    if (threadIdx.x < 4) g.info[u][threadIdx.x] = 0;
+  }
+}
+
+template <typename R>
+int launch_group_prepare(const GroupPrepT<R>& g, hipStream_t s) {
+  hipLaunchKernelGGL(group_prepare_kernel<R>, dim3((g.np + 255) / 256, g.n_units), dim3(256), 0, s, g);
+  GP_HIP(hipGetLastError());
+  return 0;
+}
+
+__global__ void group_collect_kernel(GroupCollectT g) {
+  const int u = blockIdx.x, t = threadIdx.x;
+  if (t < 64) g.scal_host[u][t] = g.scal[u][t];
+  else if (t < 68) g.info_host[u][t - 64] = g.info[u][t - 64];
+  __threadfence_system();
+}
+
+int launch_group_collect(const GroupCollectT& g, hipStream_t s) {
+  hipLaunchKernelGGL(group_collect_kernel, dim3(g.n_units), dim3(128), 0, s, g);
   GP_HIP(hipGetLastError());
   return 0;
 }
 
 // ------------------------------------------------------------------ pack / symmetrize
+// (a tile is copied by eight blocks, sixteen rows each: with one block per tile a 640 x 640 matrix had 15 blocks on
+// the chip and the copy took 21-33 us; 64 us at N = 4096)
 template <typename R>
-__global__ void pack_lower_kernel(const R* __restrict__ src, int64_t lds, int n, R* __restrict__ dst, int64_t ldd) {
+__global__ __launch_bounds__(256) void pack_lower_kernel(const R* __restrict__ src, int64_t lds, int n, R* __restrict__ dst,
+                                                         int64_t ldd) {
   const int tj = blockIdx.x, ti = blockIdx.y;
   if (tj > ti) return;
-  const int r0 = ti * TILE, c0 = tj * TILE;
-  for (int e = threadIdx.x; e < TILE * TILE; e += blockDim.x) {
+  const int r0 = ti * TILE + 16 * blockIdx.z, c0 = tj * TILE;
+#pragma unroll
+  for (int it = 0; it < 8; ++it) {
+    const int e = threadIdx.x + 256 * it;
     const int i = r0 + (e >> 7), j = c0 + (e & 127);
     R v;
     if (i < n && j < n) v = src[(int64_t)i * lds + j];
@@ -160,7 +210,7 @@ __global__ void pack_lower_kernel(const R* __restrict__ src, int64_t lds, int n,
 
 template <typename R>
 int launch_pack_lower(const R* src, int64_t lds, int n, R* dst, int64_t ldd, int np, hipStream_t s) {
-  hipLaunchKernelGGL(pack_lower_kernel<R>, dim3(np / TILE, np / TILE), dim3(256), 0, s, src, lds, n, dst, ldd);
+  hipLaunchKernelGGL(pack_lower_kernel<R>, dim3(np / TILE, np / TILE, TILE / 16), dim3(256), 0, s, src, lds, n, dst, ldd);
   GP_HIP(hipGetLastError());
   return 0;
 }
@@ -233,7 +283,8 @@ __global__ void frob_tile_kernel(const R* __restrict__ T, int64_t ldt, double* _
   }
   const R* base = T + (int64_t)ti * TILE * ldt + tj * TILE;
   double v = 0.0;
-  for (int e = threadIdx.x; e < TILE * TILE; e += blockDim.x) {
+#pragma unroll 8
+  for (int e = threadIdx.x; e < TILE * TILE; e += 256) {
     const double x = (double)base[(int64_t)(e >> 7) * ldt + (e & 127)];
     v += x * x;
   }
@@ -265,6 +316,7 @@ __global__ void trmv_lower_kernel(const R* __restrict__ L, int64_t ldl, int np, 
   if (i >= np) return;
   const R* row = L + (int64_t)i * ldl;
   double v = 0.0;
+#pragma unroll 8
   for (int j = lane; j <= i; j += 64) v += (double)row[j] * (double)x[j];
   v = wave_sum(v);
   if (lane == 0) y[i] = (R)v;
@@ -277,16 +329,17 @@ int launch_trmv_lower(const R* L, int64_t ldl, int np, const R* x, R* y, hipStre
   return 0;
 }
 
-// z_j = sum_{i >= j} L[i][j] x_i : block = 64 columns x one chunk of 512 rows
+// z_j = sum_{i >= j} L[i][j] x_i : block = 64 columns x one chunk of TRMV_ROWS rows
 template <typename R>
 __global__ void trmv_lower_t_kernel(const R* __restrict__ L, int64_t ldl, int np, const R* __restrict__ x,
                                     double* __restrict__ partial) {
   __shared__ double sh[4][64];
   const int c = threadIdx.x & 63, rl = threadIdx.x >> 6;
   const int j = blockIdx.x * 64 + c;
-  const int i0 = blockIdx.y * 512, i1 = min(np, i0 + 512);
+  const int i0 = blockIdx.y * TRMV_ROWS, i1 = min(np, i0 + TRMV_ROWS);
   double v = 0.0;
   if (i1 > blockIdx.x * 64) {
+#pragma unroll 8
     for (int i = i0 + rl; i < i1; i += 4)
       if (i >= j) v += (double)L[(int64_t)i * ldl + j] * (double)x[i];
   }
@@ -315,7 +368,7 @@ int launch_reduce_slices(const RI* src, int64_t slice_stride, int nslice, RO* ds
 
 template <typename R>
 int launch_trmv_lower_t(const R* L, int64_t ldl, int np, const R* x, R* z, double* partial, hipStream_t s) {
-  const int chunks = (np + 511) / 512;
+  const int chunks = (np + TRMV_ROWS - 1) / TRMV_ROWS;
   hipLaunchKernelGGL(trmv_lower_t_kernel<R>, dim3(np / 64, chunks), dim3(256), 0, s, L, ldl, np, x, partial);
   GP_HIP(hipGetLastError());
   return launch_reduce_slices(partial, np, chunks, z, np, s);
@@ -962,6 +1015,7 @@ int launch_fparam(const double* lam_m, const double* lam_var, const double* r, i
   template int launch_frob_lower<R>(const R*, int64_t, int, double*, double*, hipStream_t);                         \
   template int launch_trmv_lower<R>(const R*, int64_t, int, const R*, R*, hipStream_t);                             \
   template int launch_trmv_lower_t<R>(const R*, int64_t, int, const R*, R*, double*, hipStream_t);                  \
+  template int launch_group_prepare<R>(const GroupPrepT<R>&, hipStream_t);                                          \
   template int launch_dot<R>(const R*, const R*, int, double*, hipStream_t);                                        \
   template int launch_moments<R>(const R*, const R*, const R*, int64_t, const R*, int64_t, const R*, const R*, int, \
                                  double, double, R*, R*, R*, R*, double*, hipStream_t);                             \

@@ -282,7 +282,15 @@ static int gemm_list(hipStream_t s, int cnt, const R* const* Ap, const R* const*
   static const bool no_batch = getenv("GPFIT_NO_BATCH") != nullptr;   // tuning knob: every product on its own
   // epi: fused epilogue wanted (common.h); *epi_done says whether the launches carried it -- all of them or none
   // (the caller runs the separate passes otherwise)
-  if (cnt == 1 || gemm_pick_tile(g) == TILE || no_batch) {
+  // Large-tile products normally go unit by unit through the ordinary launcher (balanced schedules).  Lists that
+  // carry an epilogue (T and Q of a group) may share ONE data-parallel 128-tile launch instead once there are enough
+  // of them to fill the chip for many rounds (GPFIT_LIST_T128 = smallest such count, 0 = never): no stream-K fix-up,
+  // no partial tiles, and the epilogues (tile norms, mirrored store) ride along -- a single unit's stream-K launch
+  // cannot carry them.
+  static const int list_t128 = getenv("GPFIT_LIST_T128") ? atoi(getenv("GPFIT_LIST_T128")) : 0;
+  static const int list_t128_dim = getenv("GPFIT_LIST_T128_DIM") ? atoi(getenv("GPFIT_LIST_T128_DIM")) : 4096;
+  const bool share_t128 = epi != 0 && list_t128 > 0 && cnt >= list_t128 && M <= list_t128_dim && N <= list_t128_dim;
+  if (cnt == 1 || (gemm_pick_tile(g) == TILE && !share_t128) || no_batch) {
     bool fused = epi != 0;
     for (int i = 0; i < cnt && fused; ++i) {
       g.A = Ap[i]; g.B = Bp[i]; g.C = Cp[i];
@@ -920,6 +928,7 @@ static int fit_eval_impl(gpfit_ctx* c, void* stream, const double* theta, const 
   c->last_enqueue_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_host0).count();
   c->pend.active = true; c->pend.stream = s; c->pend.A = A; c->pend.lambda0 = lambda0; c->pend.sigma0 = th.sigma0;
   c->pend.n = n; c->pend.np = np; c->pend.d = d; c->pend.want_grad = want_grad; c->pend.elem_bytes = (int)sizeof(R);
+  c->pend.use_done = false;
   if (async_call) return 0;
   return fit_eval_finish(c, out_host);
 }
@@ -1017,17 +1026,24 @@ static int fit_eval_batch_impl(gpfit_ctx* const* cs, int nu, void* stream, const
     (void)hipEventRecord(tev[0], s);
   }
   // Everything on the caller's stream (post_join_list: a group gets its concurrency from batched launches).
-  // ---- phase 1, unit by unit: kernel build, moments, V packed
+  // ---- phase 1, unit by unit: kernel build, moments, V packed (pixel lists, info words and padded means of all
+  // units by one launch)
+  {
+    GroupPrepT<R> gp{};
+    gp.n_units = na; gp.n = n; gp.np = np;
+    for (int i = 0; i < na; ++i) {
+      gpfit_ctx* c = un[i].c;
+      gp.pix_host[i] = c->pix_host; gp.pix[i] = c->pix; gp.d[i] = un[i].d; gp.info[i] = c->info;
+      gp.m[i] = m[un[i].u]; gp.mpad[i] = RP(c->mpad);
+    }
+    GP_TRY(launch_group_prepare(gp, s));
+  }
   for (int i = 0; i < na; ++i) {
     Unit& q = un[i];
     gpfit_ctx* c = q.c;
     const int d = q.d, dp = q.dp;
     const double s0sq = q.th.sigma0 * q.th.sigma0;
     g_main_sk_ws = c0->sk_ws[0];
-    GP_HIP(hipMemsetAsync(c->info, 0, 4 * sizeof(int), s));
-    GP_HIP(hipMemcpyAsync(c->pix, c->pix_host, (size_t)d * sizeof(int), hipMemcpyHostToDevice, s));
-    GP_HIP(hipMemsetAsync(RP(c->mpad), 0, (size_t)np * sizeof(R), s));
-    GP_HIP(hipMemcpyAsync(RP(c->mpad), m[q.u], (size_t)n * sizeof(R), hipMemcpyDeviceToDevice, s));
     GP_TRY(launch_localker<R>(q.th, c->pix, d, dp, n_rows, n_cols, RP(c->Cmat), dp, nullptr, s));
     GP_TRY(launch_gather(X[q.u], ldx, n, c->pix, d, dp, np, RP(c->Xt), ld, RP(c->Xm), dp, s));
     GP_TRY(gemm<R>(s, 1, 1, dp, np, dp, 1.0, RP(c->Cmat), dp, RP(c->Xt), ld, 0.0, RP(c->XCt), ld, 0, 0, 0));
@@ -1103,11 +1119,27 @@ static int fit_eval_batch_impl(gpfit_ctx* const* cs, int nu, void* stream, const
   }
   if (mixed_grad) GP_TRY(post_join_list<float>(na, cl, pfl, thl, n, np, dl, dpl, n_rows, n_cols, want_grad, s, no_phase, false));
   else GP_TRY(post_join_list<R>(na, cl, pjl, thl, n, np, dl, dpl, n_rows, n_cols, want_grad, s, no_phase, false));
+  {
+    GroupCollectT gc{};
+    gc.n_units = na;
+    for (int i = 0; i < na; ++i) {
+      gpfit_ctx* c = un[i].c;
+      gc.scal[i] = c->scal; gc.info[i] = c->info; gc.scal_host[i] = c->scal_host; gc.info_host[i] = c->info_host;
+    }
+    GP_TRY(launch_group_collect(gc, s));
+  }
+  // one completion event for the group, recorded on the leader's context and waited on by every unit's finish
+  if (!c0->pend.done) GP_HIP(hipEventCreateWithFlags(&c0->pend.done, hipEventDisableTiming));
+  GP_HIP(hipEventRecord(c0->pend.done, s));
   for (int i = 0; i < na; ++i) {
     Unit& q = un[i];
     gpfit_ctx* c = q.c;
-    GP_HIP(hipMemcpyAsync(c->scal_host, c->scal, 64 * sizeof(double), hipMemcpyDeviceToHost, s));
-    GP_HIP(hipMemcpyAsync(c->info_host, c->info, 4 * sizeof(int), hipMemcpyDeviceToHost, s));
+    if (c != c0) {
+      // (a context's own event so that it can outlive the leader: recording is a barrier packet, no kernel)
+      if (!c->pend.done) GP_HIP(hipEventCreateWithFlags(&c->pend.done, hipEventDisableTiming));
+      GP_HIP(hipEventRecord(c->pend.done, s));
+    }
+    c->pend.use_done = true;
     c->pend.active = true; c->pend.stream = s; c->pend.A = q.A; c->pend.lambda0 = lambda0[q.u]; c->pend.sigma0 = q.th.sigma0;
     c->pend.n = n; c->pend.np = np; c->pend.d = q.d; c->pend.want_grad = want_grad; c->pend.elem_bytes = (int)sizeof(R);
   }
@@ -1601,7 +1633,8 @@ int fit_eval_finish(gpfit_ctx* c, double* out_host) {
   }
   c->pend.active = false;
   DeviceGuard device_guard(c->device);
-  GP_HIP(hipStreamSynchronize(c->pend.stream));
+  if (c->pend.use_done && c->pend.done) GP_HIP(hipEventSynchronize(c->pend.done));
+  else GP_HIP(hipStreamSynchronize(c->pend.stream));
   const int n = c->pend.n, np = c->pend.np, want_grad = c->pend.want_grad;
   const double A = c->pend.A, lambda0 = c->pend.lambda0, sigma0 = c->pend.sigma0;
 
@@ -1743,7 +1776,7 @@ int gpfit_ctx_create(int device, int64_t n_max, int64_t d_max, int64_t d_full_ma
   const size_t t64 = np / 64;
   A(&c->upart, t64 * np); A(&c->vpart, t64 * np); A(&c->sumA_part, t64 * (t64 + 1) / 2);
   A(&c->rect_part, t64 * t64);
-  A(&c->frob_part, (np / TILE) * (np / TILE + 1) / 2); A(&c->trmv_part, (np / 512 + 1) * np);
+  A(&c->frob_part, (np / TILE) * (np / TILE + 1) / 2); A(&c->trmv_part, (np / TRMV_ROWS + 1) * np);
   A(&c->scal, 64);
   for (int i = 0; i < 4 && !rc; ++i) {
     double* w = nullptr;
@@ -1787,6 +1820,7 @@ void gpfit_ctx_destroy(gpfit_ctx* c) {
   DeviceGuard device_guard(c->device);
   (void)hipDeviceSynchronize();
   for (void* p : c->allocs) (void)hipFree(p);
+  if (c->pend.done) (void)hipEventDestroy(c->pend.done);
   if (c->scal_host) (void)hipHostFree(c->scal_host);
   if (c->pix_host) (void)hipHostFree(c->pix_host);
   if (c->info_host) (void)hipHostFree(c->info_host);

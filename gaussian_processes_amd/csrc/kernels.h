@@ -21,6 +21,32 @@ int launch_chol_leaf_reg(const R* A, int64_t lda, R* L, int64_t ldl, R* Linv, in
                          hipStream_t s);
 // n independent 128 x 128 blocks in one launch (one workgroup each): block b factors A[b] into L[b], Li[b] and
 // reports into info[b]; common leading dimensions and info_base
+// Per-unit housekeeping of a group of evaluations, one launch for the whole group instead of four small copies /
+// fills per unit at the start and two device-to-host copies per unit at the end (each of those is a blit kernel with
+// a host round trip behind it: 1.8 ms per group of 16 at the end alone, profiles/r03_group_idle.txt).
+// Begin: the masked pixel list from its pinned host copy, info zeroed, the mean zero-padded to np.
+// End: the unit's 64 scalars and 4 info words written straight into its pinned (device-visible) host buffers.
+template <typename R>
+struct GroupPrepT {
+  int n_units, n, np;
+  const int* pix_host[GEMM_MAXB / 2];
+  int* pix[GEMM_MAXB / 2];
+  int d[GEMM_MAXB / 2];
+  int* info[GEMM_MAXB / 2];
+  const R* m[GEMM_MAXB / 2];
+  R* mpad[GEMM_MAXB / 2];
+};
+struct GroupCollectT {
+  int n_units;
+  const double* scal[GEMM_MAXB / 2];
+  const int* info[GEMM_MAXB / 2];
+  double* scal_host[GEMM_MAXB / 2];
+  int* info_host[GEMM_MAXB / 2];
+};
+template <typename R>
+int launch_group_prepare(const GroupPrepT<R>& g, hipStream_t s);
+int launch_group_collect(const GroupCollectT& g, hipStream_t s);
+
 template <typename R>
 struct LeafBatchT {
   const R* A[GEMM_MAXB];

@@ -176,14 +176,16 @@ class GPFitEngine:
 MAX_GROUP = 16  # units per gpfit_fit_eval_batch call (2 chains each; GEMM_MAXB = 32 problems per pointer batch)
 
 
-def fit_eval_group(engines, thetas, lower, upper, n_px_side, X, r, m, V, logA, lambda0, want_grad=True, reuse_V=False,
-                   grad_precision="native"):
+def fit_eval_group_begin(engines, thetas, lower, upper, n_px_side, X, r, m, V, logA, lambda0, want_grad=True, reuse_V=False,
+                         grad_precision="native"):
     """``len(thetas)`` independent units of the same N in ONE call (``gpfit_fit_eval_batch``): unit u on
     ``engines[u]`` with ``thetas[u]``, ``r[u]``, ``m[u]``, ``V[u]`` (``X``, ``r``, ``m``, ``V``, ``logA``, ``lambda0`` may
     each be one object shared by every unit or a list with one entry per unit).  The Cholesky recursions of all
     units run in lock step (shared launches on the latency-bound levels); results are bit-identical to
-    ``engines[u].fit_eval`` unit by unit.  Returns the list of result dicts of :meth:`GPFitEngine.fit_eval`
-    (without the per-point vectors)."""
+    ``engines[u].fit_eval`` unit by unit.  Enqueues only and returns a handle for :func:`fit_eval_group_finish`, which
+    returns the list of result dicts of :meth:`GPFitEngine.fit_eval` (without the per-point vectors); with two sets of
+    engines the next group is enqueued before the previous one is collected and the GPU never waits for the host
+    (``multi.evaluate_units_grouped``)."""
     nu = len(thetas)
     if not 1 <= nu <= MAX_GROUP or len(engines) < nu:
         raise ValueError(f"fit_eval_group: 1 .. {MAX_GROUP} units per call, one engine per unit")
@@ -223,19 +225,34 @@ def fit_eval_group(engines, thetas, lower, upper, n_px_side, X, r, m, V, logA, l
     rc = entry(ctxs, nu, e0._stream(), theta, lo, up, rows, cols, ptrs(Xs), Xs[0].stride(0), N, ptrs(rs), ptrs(ms), ptrs(Vs),
                Vs[0].stride(0), _lib.darr(logAs), _lib.darr(lam0s), flags, out, rcs)
     _lib.check(rc, "gpfit_fit_eval_batch")
-    results, first_error = [], None
-    for u in range(nu):   # every pending unit is collected, also behind a failed one
+    tickets = []
+    for u in range(nu):
         o = (ctypes.c_double * 16)(*out[16 * u:16 * u + 16])
-        ticket = {"rc": int(rcs[u]), "out": o, "pending": rcs[u] == 0, "keep": (Xs[u], rs[u], ms[u], Vs[u]),
-                  "lam_m": None, "lam_var": None, "f": None}
+        tickets.append({"rc": int(rcs[u]), "out": o, "pending": rcs[u] == 0, "keep": (Xs[u], rs[u], ms[u], Vs[u]),
+                        "lam_m": None, "lam_var": None, "f": None})
+    return {"engines": list(engines[:nu]), "tickets": tickets}
+
+
+def fit_eval_group_finish(handle):
+    """Collect the group enqueued by :func:`fit_eval_group_begin`: waits for THAT group only (a completion event
+    recorded behind its results), so a second group -- on other engines -- may already be running on the stream."""
+    results, first_error = [], None
+    for eng, ticket in zip(handle["engines"], handle["tickets"]):   # every pending unit is collected, also behind a failed one
         try:
-            results.append(engines[u].fit_eval_finish(ticket))
+            results.append(eng.fit_eval_finish(ticket))
         except _lib.GpfitError as err:
             results.append(None)
             first_error = first_error or err
     if first_error is not None:
         raise first_error
     return results
+
+
+def fit_eval_group(engines, thetas, lower, upper, n_px_side, X, r, m, V, logA, lambda0, want_grad=True, reuse_V=False,
+                   grad_precision="native"):
+    """:func:`fit_eval_group_begin` and :func:`fit_eval_group_finish` in one call."""
+    return fit_eval_group_finish(fit_eval_group_begin(engines, thetas, lower, upper, n_px_side, X, r, m, V, logA, lambda0,
+                                                      want_grad=want_grad, reuse_V=reuse_V, grad_precision=grad_precision))
 
 
 def fits_flops(N: int, d: int) -> float:

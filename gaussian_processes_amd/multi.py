@@ -112,22 +112,43 @@ def evaluate_units_pipelined(units: Sequence[int], submit_fn: Callable[[int, int
 
 
 def evaluate_units_grouped(units: Sequence[int], group_fn: Callable[[Sequence[int]], Sequence[Sequence[float]]], device,
-                           group: int) -> torch.Tensor:
+                           group: int, begin_fn=None, finish_fn=None, sets: int = 1) -> torch.Tensor:
     """Evaluate the local units ``group`` at a time: ``group_fn(us) -> [(loss, g0..g5) for u in us]`` runs one
     grouped call (``engine.fit_eval_group`` / ``gpfit_fit_eval_batch``: the Cholesky recursions of the whole group
     in lock step, the products behind them as batched launches).  Units are independent and every
-    unit's numbers are bit-identical to its own evaluation, so the table equals :func:`evaluate_units`'."""
+    unit's numbers are bit-identical to its own evaluation, so the table equals :func:`evaluate_units`'.
+
+    With ``begin_fn(us, slot) -> handle`` / ``finish_fn(handle, slot) -> rows`` and ``sets`` >= 2 sets of engines
+    (``slot`` = which set) the groups are pipelined one deep: group k + 1 is enqueued before group k is collected,
+    so the host's share of a group (argument marshalling, result collection: about 5 ms per group of 16) runs
+    beside the previous group instead of between two groups.  The table is assembled on the host and moved to the
+    device once."""
     if group < 1:
         raise ValueError("group must be at least 1")
-    out = torch.zeros((len(units), RESULT_WIDTH), dtype=torch.float64, device=device)
-    for g0 in range(0, len(units), group):
-        us = list(units[g0:g0 + group])
-        rows = group_fn(us)
-        if len(rows) != len(us):
-            raise RuntimeError(f"group_fn returned {len(rows)} results for {len(us)} units")
+    table = [None] * len(units)
+
+    def store(g0, n_us, rows):
+        if len(rows) != n_us:
+            raise RuntimeError(f"the group call returned {len(rows)} results for {n_us} units")
         for j, row in enumerate(rows):
-            out[g0 + j] = torch.as_tensor(list(row), dtype=torch.float64, device=device)
-    return out
+            table[g0 + j] = [float(v) for v in row]
+
+    pipelined = begin_fn is not None and finish_fn is not None and sets >= 2
+    pending = None
+    for gi, g0 in enumerate(range(0, len(units), group)):
+        us = list(units[g0:g0 + group])
+        if not pipelined:
+            store(g0, len(us), group_fn(us))
+            continue
+        handle = begin_fn(us, gi % sets)
+        if pending is not None:
+            store(pending[1], pending[2], finish_fn(pending[0], pending[3]))
+        pending = (handle, g0, len(us), gi % sets)
+    if pending is not None:
+        store(pending[1], pending[2], finish_fn(pending[0], pending[3]))
+    if not table:
+        return torch.zeros((0, RESULT_WIDTH), dtype=torch.float64, device=device)
+    return torch.tensor(table, dtype=torch.float64).to(device)
 
 
 def gather_results(local: torch.Tensor, n_units: int) -> torch.Tensor:
@@ -148,15 +169,17 @@ def gather_results(local: torch.Tensor, n_units: int) -> torch.Tensor:
 
 
 def run_sharded(n_units: int, eval_fn: Callable[[int], Sequence[float]], device, submit_fn=None, collect_fn=None,
-                depth: int = 2, lockstep: bool = False, group_fn=None, group: int = 0) -> torch.Tensor:
+                depth: int = 2, lockstep: bool = False, group_fn=None, group: int = 0, begin_fn=None, finish_fn=None,
+                sets: int = 1) -> torch.Tensor:
     """Evaluate all units, sharded cyclically over the ranks; with ``group_fn`` the local units go ``group`` at a
-    time through one grouped call each (:func:`evaluate_units_grouped`); with ``submit_fn`` / ``collect_fn`` they
+    time through one grouped call each (:func:`evaluate_units_grouped`; ``begin_fn`` / ``finish_fn`` / ``sets``: its
+    pipelined form); with ``submit_fn`` / ``collect_fn`` they
     are pipelined ``depth`` deep (see :func:`evaluate_units_pipelined`)."""
     world = dist.get_world_size() if dist.is_initialized() else 1
     rank = dist.get_rank() if dist.is_initialized() else 0
     mine = partition(n_units, world, rank)
-    if group_fn is not None:
-        local = evaluate_units_grouped(mine, group_fn, device, max(1, group))
+    if group_fn is not None or begin_fn is not None:
+        local = evaluate_units_grouped(mine, group_fn, device, max(1, group), begin_fn, finish_fn, sets)
     elif submit_fn is not None and collect_fn is not None:
         local = evaluate_units_pipelined(mine, submit_fn, collect_fn, device, depth, lockstep)
     else:
