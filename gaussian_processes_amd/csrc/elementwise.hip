@@ -493,24 +493,49 @@ __global__ __launch_bounds__(256) void adjoint_kernel(const R* __restrict__ W, c
   if (threadIdx.x == 0) sumA_part[blockIdx.x] = diag ? asum : 2.0 * asum;
 }
 
+// (block = 32 entries x 8 slices of the partial index, combined in a fixed order: the serial walk over N / 64
+// partials took 21 us at N = 4096 and 48 us at N = 8192 on N / 256 workgroups)
 template <typename R>
-__global__ void adjoint_u_kernel(const double* __restrict__ upart, const double* __restrict__ vpart, int nt64,
-                                 const R* __restrict__ q, const R* __restrict__ wl, int n, int np,
-                                 R* __restrict__ tvec, double* __restrict__ uq) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= np) return;
+__global__ __launch_bounds__(256) void adjoint_u_kernel(const double* __restrict__ upart, const double* __restrict__ vpart,
+                                                        int nt64, const R* __restrict__ q, const R* __restrict__ wl, int n,
+                                                        int np, R* __restrict__ tvec, double* __restrict__ uq) {
+  __shared__ double sl[8][33];
+  const int li = threadIdx.x & 31, z = threadIdx.x >> 5;
+  const int i = blockIdx.x * 32 + li;
+  double u = 0.0;
+  if (i < n) {
+    const int T = i >> 6;
+#pragma unroll 4
+    for (int t = z; t < nt64; t += 8) u += (t <= T ? upart : vpart)[(int64_t)t * np + i];
+  }
+  sl[z][li] = u;
+  __syncthreads();
+  if (z != 0 || i >= np) return;
   if (i >= n) {
     tvec[i] = (R)0;
     uq[i] = 0.0;
     return;
   }
-  const int T = i >> 6;
-  double u = 0.0;
-  for (int t = 0; t <= T; ++t) u += upart[(int64_t)t * np + i];
-  for (int t = T + 1; t < nt64; ++t) u += vpart[(int64_t)t * np + i];
+  u = sl[0][li];
+#pragma unroll
+  for (int k = 1; k < 8; ++k) u += sl[k][li];
   const double v = u / (double)q[i];
   uq[i] = v;
   tvec[i] = (R)(v - (double)wl[i]);
+}
+
+// the three sums behind the adjoint pass in one launch (block 0: uq, block 1: wl, block 2: the tile sums)
+template <typename R>
+__global__ void adjoint_sums_kernel(const double* __restrict__ uq, const R* __restrict__ wl, int n,
+                                    const double* __restrict__ sumA_part, int ntile_tri, double* __restrict__ out) {
+  __shared__ double sh[17];
+  const int b = blockIdx.x;
+  double v = 0.0;
+  if (b == 0) for (int i = threadIdx.x; i < n; i += blockDim.x) v += uq[i];
+  else if (b == 1) for (int i = threadIdx.x; i < n; i += blockDim.x) v += (double)wl[i];
+  else for (int i = threadIdx.x; i < ntile_tri; i += blockDim.x) v += sumA_part[i];
+  v = block_sum(v, sh);
+  if (threadIdx.x == 0) out[b] = v;
 }
 
 // Rectangular adjoint (x1 != x2, utils.py:996-1021 contracted with W[n1][n2]): per 64 x 64 tile
@@ -553,22 +578,51 @@ __global__ __launch_bounds__(256) void adjoint_rect_kernel(const double* __restr
   if (threadIdx.x == 0) tile_sum[ti * gridDim.x + tj] = asum;
 }
 
-// u[i] = sum_t part[t][i];  tvec = u / (2 q) (+ extra);  uq = u / q   (zero on padding)
-__global__ void adjoint_rect_reduce_kernel(const double* __restrict__ part, int nt, const double* __restrict__ q,
-                                           const double* __restrict__ extra, int n, int np,
-                                           double* __restrict__ tvec, double* __restrict__ uq) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= np) return;
+// u[i] = sum_t part[t][i];  tvec = u / (2 q) (+ extra);  uq = u / q   (zero on padding).
+// Block = 32 entries x 8 slices of the partial index (fixed order): with one thread walking all nt = N / 64 partials
+// the pass over n_t = 8192 tile rows took 44 us on 8 workgroups.
+__global__ __launch_bounds__(256) void adjoint_rect_reduce_kernel(const double* __restrict__ part, int nt,
+                                                                  const double* __restrict__ q,
+                                                                  const double* __restrict__ extra, int n, int np,
+                                                                  double* __restrict__ tvec, double* __restrict__ uq) {
+  __shared__ double sl[8][33];
+  const int li = threadIdx.x & 31, z = threadIdx.x >> 5;
+  const int i = blockIdx.x * 32 + li;
+  double u = 0.0;
+  if (i < n) {
+#pragma unroll 4
+    for (int t = z; t < nt; t += 8) u += part[(int64_t)t * np + i];
+  }
+  sl[z][li] = u;
+  __syncthreads();
+  if (z != 0 || i >= np) return;
   if (i >= n) {
     tvec[i] = 0.0;
     uq[i] = 0.0;
     return;
   }
-  double u = 0.0;
-  for (int t = 0; t < nt; ++t) u += part[(int64_t)t * np + i];
+  u = sl[0][li];
+#pragma unroll
+  for (int k = 1; k < 8; ++k) u += sl[k][li];
   const double v = u / q[i];
   uq[i] = v;
   tvec[i] = 0.5 * v + (extra ? extra[i] : 0.0);
+}
+
+// up to four independent sums in one launch (block b: out[b] = scale[b] * sum of x[b][0 .. n[b]))
+struct SumList {
+  const double* x[4];
+  int n[4];
+  double scale[4];
+  double* out[4];
+};
+__global__ void sum_list_kernel(SumList l) {
+  __shared__ double sh[17];
+  const int b = blockIdx.x;
+  double v = 0.0;
+  for (int i = threadIdx.x; i < l.n[b]; i += blockDim.x) v += l.x[b][i];
+  v = block_sum(v, sh);
+  if (threadIdx.x == 0) l.out[b][0] = l.scale[b] * v;
 }
 
 int launch_adjoint_rect(const double* W, int64_t ldw, const double* Cos, int64_t ldc, const double* q1,
@@ -578,13 +632,15 @@ int launch_adjoint_rect(const double* W, int64_t ldw, const double* Cos, int64_t
   const int g1 = np1 / 64, g2 = np2 / 64;
   hipLaunchKernelGGL(adjoint_rect_kernel, dim3(g2, g1), dim3(256), 0, s, W, ldw, Cos, ldc, q1, q2, n1, n2, np1, np2,
                      Aout, lda, upart, vpart, tile_sum);
-  hipLaunchKernelGGL(adjoint_rect_reduce_kernel, dim3((np1 + 255) / 256), dim3(256), 0, s, upart, g2, q1, extra1, n1,
+  hipLaunchKernelGGL(adjoint_rect_reduce_kernel, dim3((np1 + 31) / 32), dim3(256), 0, s, upart, g2, q1, extra1, n1,
                      np1, t1, uq1);
-  hipLaunchKernelGGL(adjoint_rect_reduce_kernel, dim3((np2 + 255) / 256), dim3(256), 0, s, vpart, g1, q2,
+  hipLaunchKernelGGL(adjoint_rect_reduce_kernel, dim3((np2 + 31) / 32), dim3(256), 0, s, vpart, g1, q2,
                      (const double*)nullptr, n2, np2, t2, uq2);
-  hipLaunchKernelGGL(sum_kernel<double>, dim3(1), dim3(1024), 0, s, tile_sum, g1 * g2, 1.0, scal3 + 0);
-  hipLaunchKernelGGL(sum_kernel<double>, dim3(1), dim3(1024), 0, s, uq1, n1, 1.0, scal3 + 1);
-  hipLaunchKernelGGL(sum_kernel<double>, dim3(1), dim3(1024), 0, s, uq2, n2, 1.0, scal3 + 2);
+  SumList l{};
+  l.x[0] = tile_sum; l.n[0] = g1 * g2; l.scale[0] = 1.0; l.out[0] = scal3 + 0;
+  l.x[1] = uq1; l.n[1] = n1; l.scale[1] = 1.0; l.out[1] = scal3 + 1;
+  l.x[2] = uq2; l.n[2] = n2; l.scale[2] = 1.0; l.out[2] = scal3 + 2;
+  hipLaunchKernelGGL(sum_list_kernel, dim3(3), dim3(1024), 0, s, l);
   GP_HIP(hipGetLastError());
   return 0;
 }
@@ -603,11 +659,9 @@ template <typename R>
 int launch_adjoint_reduce(const double* upart, const double* vpart, const double* sumA_part, int ntile,
                           int ntile_tri, const R* q, const R* wl, int n, int np, R* tvec, double* uq,
                           double* scal_out, hipStream_t s) {
-  hipLaunchKernelGGL(adjoint_u_kernel<R>, dim3((np + 255) / 256), dim3(256), 0, s, upart, vpart, ntile, q, wl, n,
+  hipLaunchKernelGGL(adjoint_u_kernel<R>, dim3((np + 31) / 32), dim3(256), 0, s, upart, vpart, ntile, q, wl, n,
                      np, tvec, uq);
-  hipLaunchKernelGGL(sum_kernel<double>, dim3(1), dim3(1024), 0, s, uq, n, 1.0, scal_out + 0);
-  hipLaunchKernelGGL(sum_kernel<R>, dim3(1), dim3(1024), 0, s, wl, n, 1.0, scal_out + 1);
-  hipLaunchKernelGGL(sum_kernel<double>, dim3(1), dim3(1024), 0, s, sumA_part, ntile_tri, 1.0, scal_out + 2);
+  hipLaunchKernelGGL(adjoint_sums_kernel<R>, dim3(3), dim3(1024), 0, s, uq, wl, n, sumA_part, ntile_tri, scal_out);
   GP_HIP(hipGetLastError());
   return 0;
 }

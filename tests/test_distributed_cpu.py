@@ -153,3 +153,34 @@ def test_grouped_driver_cuts_groups_in_unit_order():
         multi.evaluate_units_grouped([1, 2], lambda us: [[0.0] * 7], torch.device("cpu"), group=2)
     with pytest.raises(ValueError):
         multi.evaluate_units_grouped([1], group_fn, torch.device("cpu"), group=0)
+
+
+def test_grouped_driver_pipelined_keeps_one_group_in_flight():
+    """evaluate_units_grouped with begin / finish and two sets of engines: group k + 1 is enqueued (on the other
+    set) before group k is collected, never more than two groups open, every set free again before it is reused,
+    and the table equals the one-group-at-a-time table."""
+    log, open_sets = [], set()
+
+    def begin(us, slot):
+        assert slot not in open_sets, "a set of engines was reused before its group was collected"
+        open_sets.add(slot)
+        log.append(("begin", list(us), slot))
+        return {"us": list(us), "slot": slot}
+
+    def finish(handle, slot):
+        assert handle["slot"] == slot and slot in open_sets
+        open_sets.discard(slot)
+        log.append(("finish", handle["us"], slot))
+        return [[float(u)] + [float(u) + k for k in range(6)] for u in handle["us"]]
+
+    units = list(range(10, 21))
+    out = multi.evaluate_units_grouped(units, None, torch.device("cpu"), group=4, begin_fn=begin, finish_fn=finish, sets=2)
+    assert [e[0] for e in log] == ["begin", "begin", "finish", "begin", "finish", "finish"]
+    assert [e[2] for e in log if e[0] == "begin"] == [0, 1, 0] and not open_sets
+    plain = multi.evaluate_units_grouped(units, lambda us: finish(begin(us, 0), 0), torch.device("cpu"), group=4)
+    assert torch.equal(out, plain) and out[:, 0].tolist() == [float(u) for u in units]
+    # one set only: the same functions, one group at a time through group_fn
+    log.clear()
+    one = multi.evaluate_units_grouped(units, lambda us: finish(begin(us, 0), 0), torch.device("cpu"), group=4, begin_fn=begin,
+                                       finish_fn=finish, sets=1)
+    assert torch.equal(one, plain) and [e[0] for e in log] == ["begin", "finish"] * 3

@@ -150,6 +150,42 @@ def test_group_with_a_unit_outside_the_limits_and_a_failed_cholesky(dev, engines
     assert [key(a) for a in alone] == [key(g) for g in again]
 
 
+def test_two_groups_in_flight_on_two_sets_of_engines(dev, engines):
+    """fit_eval_group_begin / fit_eval_group_finish: a second group enqueued on other engines before the first is
+    collected (each finish waits for its own group's completion event, not for the stream), through the pipelined
+    driver of multi.evaluate_units_grouped -- same bits as one group at a time."""
+    from gaussian_processes_amd import multi
+    from gaussian_processes_amd.engine import fit_eval_group, fit_eval_group_begin, fit_eval_group_finish
+    N, d, units, group = 640, 64, 10, 3
+    grid, X, inp = cells(N, d, units, dev)
+    engs = engines(N, d, 2 * group)
+
+    def begin(us, slot):
+        sel = [inp[u] for u in us]
+        return fit_eval_group_begin(engs[slot * group:(slot + 1) * group], [t[3] for t in sel], LOWER, UPPER, grid, X,
+                                    [t[0] for t in sel], [t[1] for t in sel], [t[2] for t in sel], LOGA, LAM0)
+
+    def finish(handle, slot):
+        return [[o["loss"]] + [o["grad"][k] for k in KEYS] for o in fit_eval_group_finish(handle)]
+
+    piped = multi.evaluate_units_grouped(list(range(units)), None, dev, group, begin_fn=begin, finish_fn=finish, sets=2)
+    plain = multi.evaluate_units_grouped(list(range(units)), lambda us: finish(begin(us, 0), 0), dev, group)
+    assert torch.equal(piped, plain)
+    alone = [engs[0].fit_eval(t[3], LOWER, UPPER, grid, X, t[0], t[1], t[2], LOGA, LAM0, want_vectors=False) for t in inp]
+    assert [float(piped[u, 0]).hex() for u in range(units)] == [float(a["loss"]).hex() for a in alone]
+    # a handle collected late, behind a later group on the same stream, still holds its own results
+    h0 = begin([0, 1, 2], 0)
+    h1 = begin([3, 4, 5], 1)
+    r1, r0 = finish(h1, 1), finish(h0, 0)
+    assert [r[0] for r in r0 + r1] == [float(piped[u, 0]) for u in range(6)]
+    with pytest.raises(_lib.GpfitError, match="pending"):
+        h = begin([0, 1, 2], 0)
+        try:
+            begin([3, 4, 5], 0)          # the same engines again before they were collected
+        finally:
+            finish(h, 0)
+
+
 def test_group_argument_checks(dev, engines):
     from gaussian_processes_amd.engine import fit_eval_group, MAX_GROUP
     N, d = 256, 64
