@@ -73,7 +73,8 @@ struct GemmArgsT {
   //   1  mirror: square lower output, every stored element below the diagonal is also stored transposed
   //      (replaces a symmetrisation pass over the matrix)
   //   2  tile norms: sumsq[ti (ti + 1) / 2 + tj] = sum of squares of the stored values of 128-tile (ti, tj)
-  //      (lower output, 128-tile launches only; replaces a pass over the matrix)
+  //      (lower output, 128-tile launches only; replaces a pass over the matrix; on the stream-K schedule split
+  //      tiles leave theirs per fix-up band behind the per-tile table: gemm_sumsq_entries)
   //   4  dual update: with D = aux (same leading dimension as C), C = alpha op(A) op(B) + D and then
   //      aux = C + D (beta is ignored; replaces a copy and an axpby pass)
   int epi;
@@ -109,6 +110,11 @@ template <typename R> int launch_gemm_xcd(const GemmArgsT<R>& a, hipStream_t s);
 // would launch_gemm run these arguments on a data-parallel schedule (plain or XCD-aware), i.e. honour a.epi?
 template <typename R> bool gemm_epilogue_ok(const GemmArgsT<R>& a);
 template <typename R> bool gemm_streamk_applies(const GemmArgsT<R>& a);   // gemm_streamk.hip
+template <typename R> bool gemm_streamk_carries(const GemmArgsT<R>& a);   // gemm_streamk.hip: it would also honour a.epi
+// entries of a.sumsq an epi-2 launch of these arguments writes (0: the launch cannot carry the epilogue): nt =
+// tiles of the lower output on the data-parallel schedules (one per tile), 33 nt on the stream-K schedule (one per
+// tile + one per fix-up band); the squared Frobenius norm is the sum over all of them either way
+template <typename R> int gemm_sumsq_entries(const GemmArgsT<R>& a);
 template <typename R> bool gemm_xcd_applies(const GemmArgsT<R>& a);       // gemm_sched.hip
 
 // Arc-cosine Gram matrix from the k-major, zero-padded operands XCt[Kd][ld1], Xt[Kd][ld2]:

@@ -270,8 +270,10 @@ template <typename R>
 static int gemm_list(hipStream_t s, int cnt, const R* const* Ap, const R* const* Bp, R* const* Cp, int a_kmajor,
                      int b_kmajor, int M, int N, int K, double alpha, int64_t lda, int64_t ldb, double beta, int64_t ldc,
                      int out_lower, int a_tri, int b_tri, int reverse = 0, int ws_id = 0, void* sk_ws = nullptr,
-                     int epi = 0, R* const* auxp = nullptr, double* const* sumsqp = nullptr, bool* epi_done = nullptr) {
+                     int epi = 0, R* const* auxp = nullptr, double* const* sumsqp = nullptr, bool* epi_done = nullptr,
+                     int* sumsq_entries = nullptr) {
   if (epi_done) *epi_done = false;
+  if (sumsq_entries) *sumsq_entries = 0;
   if (cnt <= 0) return 0;
   if (cnt > GEMM_MAXB) {
     set_error("gemm_list: more problems than a pointer batch holds");
@@ -303,6 +305,11 @@ static int gemm_list(hipStream_t s, int cnt, const R* const* Ap, const R* const*
       GP_TRY(run_gemm(s, g));
     }
     if (epi_done) *epi_done = fused;
+    if (fused && sumsq_entries) {
+      g.A = Ap[0]; g.B = Bp[0]; g.C = Cp[0];
+      g.epi = epi; g.aux = auxp ? auxp[0] : nullptr; g.sumsq = sumsqp ? sumsqp[0] : nullptr;
+      *sumsq_entries = gemm_sumsq_entries(g);
+    }
     return 0;
   }
   g.nptr = cnt;
@@ -314,6 +321,7 @@ static int gemm_list(hipStream_t s, int cnt, const R* const* Ap, const R* const*
   g.epi = epi;
   if (epi && !gemm_epilogue_ok(g)) g.epi = 0;
   if (epi_done) *epi_done = g.epi != 0;
+  if (g.epi && sumsq_entries) *sumsq_entries = gemm_sumsq_entries(g);
   return run_gemm(s, g);
 }
 
@@ -622,11 +630,12 @@ static int post_join_list(int cnt, gpfit_ctx* const* cs, const PostJoin<R>* a, c
   {
     for (int i = 0; i < cnt; ++i) { Ap[i] = a[i].Li; Bp[i] = a[i].LV; Cp[i] = a[i].T; Sp[i] = cs[i]->frob_part; }
     bool normed = false;
+    int norm_entries = 0;
     // the tiles leave their sums of squares behind (no separate pass over T) where the launch can carry the epilogue
     GP_TRY(gemm_list<R>(s, cnt, Ap, Bp, Cp, 0, 1, np, np, np, 1.0, ld, ld, 0.0, ld, 1, 1, 1, walks()[3], 0, cs[0]->sk_ws[0],
-                        (fused_epilogues() & 2) ? 2 : 0, nullptr, Sp, &normed));
+                        (fused_epilogues() & 2) ? 2 : 0, nullptr, Sp, &normed, &norm_entries));
     for (int i = 0; i < cnt; ++i) {
-      if (normed) GP_TRY(launch_frob_finish(cs[i]->frob_part, (np / TILE) * (np / TILE + 1) / 2, cs[i]->scal + 5, s));
+      if (normed) GP_TRY(launch_frob_finish(cs[i]->frob_part, norm_entries, cs[i]->scal + 5, s));
       else GP_TRY(launch_frob_lower(a[i].T, ld, np, cs[i]->scal + 5, cs[i]->frob_part, s));
     }
   }
@@ -851,7 +860,7 @@ static int fit_eval_impl(gpfit_ctx* c, void* stream, const double* theta, const 
     GP_TRY(launch_gram(g, s));
   }
   GP_TRY(launch_moments(RP(c->Kvec), RP(c->q), RP(c->Cos), ld, V, ldv, m, r, n, A, lambda0, RP(c->lam_m), RP(c->lam_var), RP(c->fvec),
-                        RP(c->wl), c->scal, s));
+                        RP(c->wl), c->scal, c->sumA_part, c->info + 2, s));
   phase(1, s);
   // tuning knob: start the V chain only when the K~ chain has factored its leading block of this size
   static const int v_after = getenv("GPFIT_V_AFTER") ? atoi(getenv("GPFIT_V_AFTER")) : 0;
@@ -1056,7 +1065,7 @@ static int fit_eval_batch_impl(gpfit_ctx* const* cs, int nu, void* stream, const
       GP_TRY(launch_gram(g, s));
     }
     GP_TRY(launch_moments(RP(c->Kvec), RP(c->q), RP(c->Cos), ld, V[q.u], ldv, m[q.u], r[q.u], n, q.A, lambda0[q.u], RP(c->lam_m),
-                          RP(c->lam_var), RP(c->fvec), RP(c->wl), c->scal, s));
+                          RP(c->lam_var), RP(c->fvec), RP(c->wl), c->scal, c->sumA_part, c->info + 2, s));
     if (!q.reuse_V) {
       c->lv_valid = false; c->lv32_valid = false;
       GP_TRY(launch_pack_lower(V[q.u], ldv, n, RP(c->Vbuf), ld, np, s));
@@ -1092,8 +1101,8 @@ static int fit_eval_batch_impl(gpfit_ctx* const* cs, int nu, void* stream, const
     gpfit_ctx* c = q.c;
     const int dp = q.dp;
     cl[i] = c; thl[i] = q.th; dl[i] = q.d; dpl[i] = dp;
-    if (!q.reuse_V) GP_TRY(launch_logdet(RP(c->LVbuf), ld, n, c->scal + 40, s));
-    GP_TRY(launch_logdet(RP(c->Lbuf), ld, n, c->scal + 3, s));
+    if (!q.reuse_V) GP_TRY(launch_logdet_pair(RP(c->Lbuf), c->scal + 3, RP(c->LVbuf), c->scal + 40, ld, n, s));
+    else GP_TRY(launch_logdet(RP(c->Lbuf), ld, n, c->scal + 3, s));
     GP_TRY(launch_trmv_lower(RP(c->Libuf), ld, np, RP(c->mpad), RP(c->yv), s));
     GP_TRY(launch_dot(RP(c->yv), RP(c->yv), np, c->scal + 6, s));
     GP_TRY(launch_trmv_lower_t(RP(c->Libuf), ld, np, RP(c->yv), RP(c->bv), c->trmv_part, s));
@@ -1776,7 +1785,7 @@ int gpfit_ctx_create(int device, int64_t n_max, int64_t d_max, int64_t d_full_ma
   const size_t t64 = np / 64;
   A(&c->upart, t64 * np); A(&c->vpart, t64 * np); A(&c->sumA_part, t64 * (t64 + 1) / 2);
   A(&c->rect_part, t64 * t64);
-  A(&c->frob_part, (np / TILE) * (np / TILE + 1) / 2); A(&c->trmv_part, (np / TRMV_ROWS + 1) * np);
+  A(&c->frob_part, 33 * (np / TILE) * (np / TILE + 1) / 2); A(&c->trmv_part, (np / TRMV_ROWS + 1) * np);
   A(&c->scal, 64);
   for (int i = 0; i < 4 && !rc; ++i) {
     double* w = nullptr;

@@ -311,10 +311,21 @@ bool gemm_epilogue_ok(const GemmArgsT<R>& a) {
   if (a.nptr > 0) return true;   // pointer batches are always data-parallel
   if (T == TILE && a.tile_limit == 0) {
     if ((a.reverse & 8) && gemm_xcd_applies(a)) return true;
-    if (gemm_streamk_applies(a)) return false;
+    if (gemm_streamk_applies(a)) return gemm_streamk_carries(a);
   }
   return true;
 }
+
+template <typename R>
+int gemm_sumsq_entries(const GemmArgsT<R>& a) {
+  if (!(a.epi & 2) || !gemm_epilogue_ok(a)) return 0;
+  const int t = a.M / TILE, nt = t * (t + 1) / 2;
+  if (a.nptr > 0 || a.half_occ || a.tile_limit != 0 || a.batch > 1) return nt;
+  if ((a.reverse & 8) && gemm_xcd_applies(a)) return nt;
+  return gemm_streamk_applies(a) ? 33 * nt : nt;
+}
+template int gemm_sumsq_entries<double>(const GemmArgsT<double>&);
+template int gemm_sumsq_entries<float>(const GemmArgsT<float>&);
 template bool gemm_epilogue_ok<double>(const GemmArgsT<double>&);
 template bool gemm_epilogue_ok<float>(const GemmArgsT<float>&);
 

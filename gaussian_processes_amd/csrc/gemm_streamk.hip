@@ -52,11 +52,30 @@ struct SkParams {
   int ntiles;
   int total, per_block;
   R* partial;
+  // fused epilogues (common.h GemmArgsT::epi, bits 1 and 2 only; lower square output, every tile on the stream-K
+  // schedule).  Tile norms: a tile finished by one workgroup leaves its sum of squares in sumsq[idx], idx =
+  // ti (ti + 1) / 2 + tj; a split tile is finished by the 32 bands of the fix-up kernel, which leave theirs in
+  // sumsq[nt_all + 32 idx + band].  The other entries of a tile are written as zero, so the sum over all
+  // 33 nt_all entries is the squared Frobenius norm whatever the cut.
+  double* sumsq;
+  int nt_all;
 };
 
 constexpr int SK_SLOTS = 512;  // resident workgroups: 256 CUs x 2 (189 VGPRs, 64 KiB LDS each)
 
+// one segment of a tile's k range (its own function so that the kernel's epilogue variants share ONE call site of the
+// main loop: the host pass of the compiler rejects a second instantiation context of the same main-loop specialisation)
 template <typename R, bool A_KMAJOR, bool B_KMAJOR>
+__device__ __forceinline__ void sk_segment(const SkParams<R>& p, const SkTile& tl, int kb, int ke, R* smem,
+                                           typename Real<R>::acc_t (&acc)[4][4]) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = acc_zero<R>();
+  gemm_mainloop<R, A_KMAJOR, B_KMAJOR, false, TILE>(p.A, p.lda, p.B, p.ldb, p.M, p.N, tl.row0, tl.col0, kb, ke, smem, acc);
+}
+
+template <typename R, bool A_KMAJOR, bool B_KMAJOR, int EPI = 0>
 __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_streamk_kernel(SkParams<R> p) {
   constexpr int KT = Real<R>::KT;
   __shared__ __attribute__((aligned(16))) R smem[4 * KT * TILE];
@@ -76,13 +95,45 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_streamk_kernel(SkParams<
     const int s1 = min(it_end, tend);
     const int kb = tl.kbeg + (it - tbeg) * KT, ke = tl.kbeg + (s1 - tbeg) * KT;
     typename Real<R>::acc_t acc[4][4];
+    sk_segment<R, A_KMAJOR, B_KMAJOR>(p, tl, kb, ke, smem, acc);
+    bool whole_done = false;
+    if constexpr (EPI != 0) {
+     if (it == tbeg && s1 == tend) {
+      whole_done = true;
+      R* __restrict__ C = p.C;
+      const int64_t ldc = p.ldc;
+      const R alpha = (R)p.alpha, beta = (R)p.beta;
+      double ss = 0.0;
+      for_each_acc<R, TILE>(acc, tl.row0, tl.col0, [&](int row, int col, R v) {
+        R* c = C + (int64_t)row * ldc + col;
+        R o = alpha * v;
+        if (beta != (R)0) o += beta * (*c);
+        if (EPI & 1) {
+          // the diagonal tile's strict upper part comes from the transposed store of its lower part
+          if (row >= col) *c = o;
+          if (row > col) C[(int64_t)col * ldc + row] = o;
+        } else {
+          *c = o;
+        }
+        if (EPI & 2) ss += (double)o * (double)o;
+      });
+      if (EPI & 2) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) acc[i][j] = acc_zero<R>();
-    gemm_mainloop<R, A_KMAJOR, B_KMAJOR, false, TILE>(p.A, p.lda, p.B, p.ldb, p.M, p.N, tl.row0, tl.col0, kb, ke,
-                                                   smem, acc);
-    if (it == tbeg && s1 == tend) {
+        for (int o = 32; o > 0; o >>= 1) ss += __shfl_down(ss, o);
+        double* red = reinterpret_cast<double*>(smem);
+        __syncthreads();  // every wave is done with the operand stages
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ss;
+        __syncthreads();
+        const int ti = tl.row0 / TILE, tj = tl.col0 / TILE;
+        const int64_t idx = (int64_t)ti * (ti + 1) / 2 + tj;
+        if (threadIdx.x == 0) p.sumsq[idx] = (red[0] + red[1]) + (red[2] + red[3]);
+        if (threadIdx.x < 32) p.sumsq[p.nt_all + 32 * idx + threadIdx.x] = 0.0;
+        __syncthreads();  // red lives in the first operand stage
+      }
+     }
+    }
+    if (whole_done) {
+    } else if (it == tbeg && s1 == tend) {
       R* __restrict__ C = p.C;
       const int64_t ldc = p.ldc;
       const R alpha = (R)p.alpha, beta = (R)p.beta;
@@ -106,7 +157,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_streamk_kernel(SkParams<
 }
 
 // C tile = alpha * (sum of its partial slots, in plan order) + beta * C
-template <typename R>
+template <typename R, int EPI = 0>
 __global__ __launch_bounds__(256) void streamk_fixup_kernel(SkParams<R> p, const int* __restrict__ fix_tile,
                                                             const int* __restrict__ fix_ptr,
                                                             const int* __restrict__ fix_slot) {
@@ -120,6 +171,7 @@ __global__ __launch_bounds__(256) void streamk_fixup_kernel(SkParams<R> p, const
   const int s0 = fix_ptr[blockIdx.x], s1 = fix_ptr[blockIdx.x + 1];
   const R alpha = (R)p.alpha, beta = (R)p.beta;
   const int band = TILE / (int)gridDim.y;
+  double ss = 0.0;
   for (int e = threadIdx.x * EPC; e < band * TILE; e += blockDim.x * EPC) {
     const int r = blockIdx.y * band + (e >> 7), c = e & 127;
     const int64_t off = (int64_t)r * TILE + c;
@@ -134,7 +186,36 @@ __global__ __launch_bounds__(256) void streamk_fixup_kernel(SkParams<R> p, const
     }
     for (; s < s1; ++s) sum += *reinterpret_cast<const V*>(p.partial + (int64_t)fix_slot[s] * (TILE * TILE) + off);
     V* cp = reinterpret_cast<V*>(p.C + (int64_t)(tl.row0 + r) * p.ldc + tl.col0 + c);
-    *cp = (beta == (R)0) ? alpha * sum : alpha * sum + beta * (*cp);
+    const V val = (beta == (R)0) ? alpha * sum : alpha * sum + beta * (*cp);
+    if constexpr ((EPI & 1) != 0) {
+      // mirrored store (as the data-parallel epilogue: the lower part is the one that counts on a diagonal tile)
+      const int grow = tl.row0 + r;
+#pragma unroll
+      for (int q = 0; q < EPC; ++q) {
+        const int gcol = tl.col0 + c + q;
+        if (grow >= gcol) p.C[(int64_t)grow * p.ldc + gcol] = val[q];
+        if (grow > gcol) p.C[(int64_t)gcol * p.ldc + grow] = val[q];
+      }
+    } else {
+      *cp = val;
+    }
+    if constexpr ((EPI & 2) != 0) {
+#pragma unroll
+      for (int q = 0; q < EPC; ++q) ss += (double)val[q] * (double)val[q];
+    }
+  }
+  if constexpr ((EPI & 2) != 0) {
+    __shared__ double red[4];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) ss += __shfl_down(ss, o);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ss;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const int ti = tl.row0 / TILE, tj = tl.col0 / TILE;
+      const int64_t idx = (int64_t)ti * (ti + 1) / 2 + tj;
+      p.sumsq[p.nt_all + 32 * idx + blockIdx.y] = (red[0] + red[1]) + (red[2] + red[3]);
+      if (blockIdx.y == 0) p.sumsq[idx] = 0.0;
+    }
   }
 }
 
@@ -259,10 +340,25 @@ bool gemm_streamk_applies(const GemmArgsT<R>& a) { return streamk_first_tile(a) 
 template bool gemm_streamk_applies<double>(const GemmArgsT<double>&);
 template bool gemm_streamk_applies<float>(const GemmArgsT<float>&);
 
+// Fused epilogues on the stream-K schedule: mirror (1) and tile norms (2) of a square lower output whose tiles ALL
+// take the stream-K schedule (the launches with operands triangular on both sides: T = L^-1 L_V and Q = I - T T^T
+// of a unit below the size where the XCD-aware tables take over), in the operand layouts the fit uses.
+template <typename R>
+bool gemm_streamk_carries(const GemmArgsT<R>& a) {
+  if (streamk_first_tile(a) != 0) return false;
+  if (!a.out_lower || a.M != a.N || a.a_kmajor) return false;
+  if (a.epi == 2) return a.b_kmajor && a.sumsq != nullptr;
+  if (a.epi == 1) return !a.b_kmajor;
+  return false;
+}
+template bool gemm_streamk_carries<double>(const GemmArgsT<double>&);
+template bool gemm_streamk_carries<float>(const GemmArgsT<float>&);
+
 template <typename R>
 int launch_gemm_streamk(const GemmArgsT<R>& a, hipStream_t s) {
   const int first = streamk_first_tile(a);
-  if (first < 0 || a.epi) return 1;   // fused epilogues live in the data-parallel kernels only
+  if (first < 0) return 1;
+  if (a.epi && !gemm_streamk_carries(a)) return 1;   // the other fused epilogues live in the data-parallel kernels only
   int device = 0;
   GP_HIP(hipGetDevice(&device));
   SkPlan plan;
@@ -295,19 +391,39 @@ int launch_gemm_streamk(const GemmArgsT<R>& a, hipStream_t s) {
   p.A = a.A; p.B = a.B; p.C = a.C; p.lda = a.lda; p.ldb = a.ldb; p.ldc = a.ldc; p.M = a.M; p.N = a.N;
   p.alpha = a.alpha; p.beta = a.beta; p.tiles = plan.tiles; p.ntiles = plan.ntiles; p.total = plan.total;
   p.per_block = plan.per_block; p.partial = (R*)(a.sk_ws ? a.sk_ws : fallback_ws);
+  p.sumsq = a.sumsq; p.nt_all = (a.M / TILE) * (a.M / TILE + 1) / 2;
   dim3 grid(plan.blocks), block(GEMM_THREADS);
   const int sel = (a.a_kmajor ? 2 : 0) | (a.b_kmajor ? 1 : 0);
-  switch (sel) {
+  if (a.epi == 0) switch (sel) {
     case 0: hipLaunchKernelGGL((gemm_streamk_kernel<R, false, false>), grid, block, 0, s, p); break;
     case 1: hipLaunchKernelGGL((gemm_streamk_kernel<R, false, true>), grid, block, 0, s, p); break;
     case 2: hipLaunchKernelGGL((gemm_streamk_kernel<R, true, false>), grid, block, 0, s, p); break;
     case 3: hipLaunchKernelGGL((gemm_streamk_kernel<R, true, true>), grid, block, 0, s, p); break;
   }
-  if (plan.nfix)
-    hipLaunchKernelGGL(streamk_fixup_kernel<R>, dim3(plan.nfix, 32), dim3(256), 0, s, p, plan.fix_tile, plan.fix_ptr,
-                       plan.fix_slot);
-  GP_HIP(hipGetLastError());
-  return 0;
+  if (a.epi == 0) {
+    if (plan.nfix)
+      hipLaunchKernelGGL(streamk_fixup_kernel<R>, dim3(plan.nfix, 32), dim3(256), 0, s, p, plan.fix_tile, plan.fix_ptr,
+                         plan.fix_slot);
+    GP_HIP(hipGetLastError());
+    return 0;
+  }
+  if (a.epi == 2) {
+    hipLaunchKernelGGL((gemm_streamk_kernel<R, false, true, 2>), grid, block, 0, s, p);
+    if (plan.nfix)
+      hipLaunchKernelGGL((streamk_fixup_kernel<R, 2>), dim3(plan.nfix, 32), dim3(256), 0, s, p, plan.fix_tile, plan.fix_ptr,
+                         plan.fix_slot);
+    GP_HIP(hipGetLastError());
+    return 0;
+  }
+  if (a.epi == 1) {
+    hipLaunchKernelGGL((gemm_streamk_kernel<R, false, false, 1>), grid, block, 0, s, p);
+    if (plan.nfix)
+      hipLaunchKernelGGL((streamk_fixup_kernel<R, 1>), dim3(plan.nfix, 32), dim3(256), 0, s, p, plan.fix_tile, plan.fix_ptr,
+                         plan.fix_slot);
+    GP_HIP(hipGetLastError());
+    return 0;
+  }
+  return 1;
 }
 
 template int launch_gemm_streamk<double>(const GemmArgsT<double>&, hipStream_t);

@@ -83,6 +83,7 @@ int launch_pack_lower(const R* src, int64_t lds, int n, R* dst, int64_t ldd, int
 template <typename R> int launch_symmetrize(R* A, int64_t lda, int n, hipStream_t s);
 // out[0] = 2*sum_i log(L_ii), i < n
 template <typename R> int launch_logdet(const R* L, int64_t ldl, int n, double* out, hipStream_t s);
+template <typename R> int launch_logdet_pair(const R* L0, double* out0, const R* L1, double* out1, int64_t ldl, int n, hipStream_t s);
 // out[0] = sum over the lower-triangular tiles of T^2 (T has exact zeros above its diagonal)
 template <typename R>
 int launch_frob_lower(const R* T, int64_t ldt, int np, double* out, double* partial, hipStream_t s);
@@ -100,7 +101,7 @@ template <typename R> int launch_dot(const R* x, const R* y, int n, double* out,
 template <typename R>
 int launch_moments(const R* Kvec, const R* q, const R* Cos, int64_t ldc, const R* V, int64_t ldv, const R* m,
                    const R* r, int n, double A, double lambda0, R* lam_m, R* lam_var, R* f, R* wl, double* scal,
-                   hipStream_t s);
+                   double* part, int* ticket, hipStream_t s);   // part: 3 ceil(n / 256) doubles; ticket: 0 between calls
 
 // Adjoint pass over the lower tiles of W (np x np):
 //   w = W_ij - 1/2 b_i b_j ; Aw = w (pi - acos c)/pi ; Bm = w sqrt(1-c^2)/pi
