@@ -298,9 +298,11 @@ def main():
     ap.add_argument("--group", type=int, default=None,
                     help="independent units per grouped call (gpfit_fit_eval_batch: their factorisations in lock step, "
                          "batched launches); default 16 for cells64, 8 for thetagrid; 0 = the pipelined driver of --depth")
-    ap.add_argument("--sets", type=int, default=2,
+    ap.add_argument("--sets", type=int, default=None,
                     help="sets of --group engines for the grouped configurations: with 2 the next group is enqueued before the "
-                         "previous one is collected (the host's share of a group runs beside the GPU's); 1 = one group at a time")
+                         "previous one is collected (the host's share of a group runs beside the GPU's); 1 = one group at a time. "
+                         "Default 2 for cells64, 1 for thetagrid (a second set of 8192-sized contexts is 60 GB for a host share "
+                         "of 2 %% of a group)")
     ap.add_argument("--depth", type=int, default=None,
                     help="with --group 0: independent units kept in flight per GPU on as many contexts (default 3)")
     ap.add_argument("--cpu-sample-n", type=int, default=4096)
@@ -320,6 +322,8 @@ def main():
         args.depth = 3   # measured optimum for both configs this round (cells64: 148 / 183 / 168 / 166 / 168 cells/s at 2..6)
     if args.group is None:
         args.group = {"cells64": 16, "thetagrid": 8}.get(args.config, 0)
+    if args.sets is None:
+        args.sets = 2 if args.config == "cells64" else 1
     dtype_name = args.dtype or ("mixed" if args.config == "thetagrid" else "f64")
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -603,6 +607,14 @@ def main():
             eng.set_profile(2)
             probe()
             phases = eng.get_phases()
+        executed_job = None
+        if args.config == "thetagrid":
+            # the timed lattice points reuse their context's V factor: their executed flops come from a probe that does too
+            eng.set_profile(1)
+            eng.fit_eval(points[0], lower, upper, grid, Xd, rd, md, Vd, logA, lam0, want_grad=want_grad, want_vectors=False,
+                         grad_precision=gprec, reuse_V=True)
+            pr = eng.get_profile()
+            executed_job = pr["gemm_flops"] + pr["small_gemm_flops"] + pr["gram_flops"]
         eng.set_profile(0)
         unit_ms = phases["end"] if phases else ms_per_step
         gemm_tflops = prof["gemm_flops"] / (prof["gemm_ms"] * 1e-3) / 1e12 if prof["gemm_ms"] > 0 else 0.0
@@ -627,7 +639,8 @@ def main():
             dom_name = f"gemm_epi_kernel<{rname}, false, true, 2>" if fused_norm else f"gemm_xcd_kernel<{rname}, false, true>"
             dom_how = "XCD-aware macro-tile schedule"
         elif t_tiles >= 384:
-            dom_name, dom_how = f"gemm_streamk_kernel<{rname}, false, true>", "stream-K schedule; the live figure includes its fix-up kernel"
+            dom_name = f"gemm_streamk_kernel<{rname}, false, true, {2 if fused_norm else 0}>"
+            dom_how = "stream-K schedule" + (" with the tile-norm epilogue" if fused_norm else "") + "; the live figure includes its fix-up kernel"
         else:
             dom_name, dom_how = None, None
         measured = prof["largest_gemm_ms"] > 0 and dom_name is not None
@@ -679,6 +692,12 @@ def main():
             "unit_ms": round(unit_ms, 3),
             "unit_executed_tflops": round(executed / (unit_ms * 1e-3) / 1e12, 2),
             "unit_executed_frac": round(executed / (unit_ms * 1e-3) / 1e12 / peak, 4),
+            # configurations of many units: the unit_* fields above describe ONE unit evaluated on its own (the profiled
+            # probe); the timed job runs them in groups, and its utilisation is the same executed flops per unit times the
+            # measured units per second (all GPUs)
+            "job_executed_tflops": None if units_per_step <= 1 else round((executed_job or executed) * units_per_s / 1e12 / world, 2),
+            "job_executed_frac": None if units_per_step <= 1 else round((executed_job or executed) * units_per_s / 1e12 / world / peak, 4),
+            "job_flops_executed_per_unit": None if units_per_step <= 1 else (executed_job or executed),
             "phases_ms": phases,
             "gemm_ms_per_fit": round(prof["gemm_ms"], 3), "leaf_ms_per_fit": round(prof["leaf_ms"], 3),
             "leaf_launches_per_fit": prof["leaf_launches"],
