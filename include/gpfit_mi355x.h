@@ -140,7 +140,9 @@ int gpfit_fit_eval(gpfit_ctx* ctx, void* stream, const double* theta, const doub
 
 /* Collect the evaluation enqueued on `ctx` by gpfit_fit_eval / gpfit_fit_eval_f32 with bit 2 of
  * want_grad: waits for its stream, writes out_host[16] and returns what the synchronous call
- * would have returned (0 or the LAPACK info).  -3 if nothing is pending. */
+ * would have returned (0 or the LAPACK info).  -3 if nothing is pending.  A unit enqueued by
+ * gpfit_fit_eval_batch waits for its GROUP's completion event instead of the stream, so a later group (on other
+ * contexts) may already be running on the same stream while this one is collected. */
 int gpfit_fit_eval_finish(gpfit_ctx* ctx, double* out_host);
 
 /* n_units (1 .. 16) independent units of work of the same N in one call -- the cells / hyperparameter-grid
@@ -152,7 +154,10 @@ int gpfit_fit_eval_finish(gpfit_ctx* ctx, double* out_host);
  * fill the chip.  Each unit's results are bit-identical to gpfit_fit_eval on its own.  want_grad: bits 0, 1, 3
  * as gpfit_fit_eval; the call is always asynchronous: rc_out[u] = 0 -> collect unit u with
  * gpfit_fit_eval_finish(ctxs[u], ...); -2 -> theta outside the limits, out_host[16 u ..] already holds the
- * infinite loss / gradients and nothing is pending.  Returns 0 or < 0 (bad argument / capacity / HIP error). */
+ * infinite loss / gradients and nothing is pending.  A group's per-unit housekeeping is two launches (pixel
+ * lists / info words / padded means at the start; the 64 result scalars and info words of every unit written
+ * straight into its pinned host buffers at the end, followed by the completion event gpfit_fit_eval_finish waits
+ * for).  Returns 0 or < 0 (bad argument / capacity / HIP error). */
 int gpfit_fit_eval_batch(gpfit_ctx* const* ctxs, int n_units, void* stream, const double* theta,
                          const double* lower, const double* upper, int n_rows, int n_cols,
                          const double* const* X, int64_t ldx, int64_t N, const double* const* r,
