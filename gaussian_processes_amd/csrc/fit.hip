@@ -1798,9 +1798,12 @@ int gpfit_ctx_create(int device, int64_t n_max, int64_t d_max, int64_t d_full_ma
     gpfit_ctx_destroy(c);
     return rc;
   }
-  GP_HIP(hipHostMalloc((void**)&c->scal_host, 64 * sizeof(double)));
-  GP_HIP(hipHostMalloc((void**)&c->pix_host, (size_t)c->dfull_cap * sizeof(int)));
-  GP_HIP(hipHostMalloc((void**)&c->info_host, 4 * sizeof(int)));
+  // pinned AND mapped into the device's address space: the group kernels read pix_host and write scal_host / info_host
+  // directly (elementwise.hip: group_prepare_kernel, group_collect_kernel)
+  constexpr unsigned HOST_FLAGS = hipHostMallocMapped | hipHostMallocPortable;
+  GP_HIP(hipHostMalloc((void**)&c->scal_host, 64 * sizeof(double), HOST_FLAGS));
+  GP_HIP(hipHostMalloc((void**)&c->pix_host, (size_t)c->dfull_cap * sizeof(int), HOST_FLAGS));
+  GP_HIP(hipHostMalloc((void**)&c->info_host, 4 * sizeof(int), HOST_FLAGS));
   {
     // the V chain is the shorter of the two factorisations: give its stream the lowest priority so
     // that, whenever both have workgroups ready, the critical K~ chain is dispatched first
