@@ -297,7 +297,7 @@ def main():
     ap.add_argument("--grid-points", type=int, default=512)
     ap.add_argument("--group", type=int, default=None,
                     help="independent units per grouped call (gpfit_fit_eval_batch: their factorisations in lock step, "
-                         "batched launches); default 16 for cells64, 8 for thetagrid; 0 = the pipelined driver of --depth")
+                         "batched launches); default 16 for cells64 and thetagrid; 0 = the pipelined driver of --depth")
     ap.add_argument("--sets", type=int, default=None,
                     help="sets of --group engines for the grouped configurations: with 2 the next group is enqueued before the "
                          "previous one is collected (the host's share of a group runs beside the GPU's); 1 = one group at a time. "
@@ -321,7 +321,7 @@ def main():
     if args.depth is None:
         args.depth = 3   # measured optimum for both configs this round (cells64: 148 / 183 / 168 / 166 / 168 cells/s at 2..6)
     if args.group is None:
-        args.group = {"cells64": 16, "thetagrid": 8}.get(args.config, 0)
+        args.group = {"cells64": 16, "thetagrid": 16}.get(args.config, 0)   # thetagrid: 16 contexts of N = 8192 are 118 GB
     if args.sets is None:
         args.sets = 2 if args.config == "cells64" else 1
     dtype_name = args.dtype or ("mixed" if args.config == "thetagrid" else "f64")
