@@ -52,7 +52,7 @@ struct SkParams {
   int ntiles;
   int total, per_block;
   R* partial;
-  // fused epilogues (common.h GemmArgsT::epi, bits 1 and 2 only; lower square output, every tile on the stream-K
+  // fused epilogue (common.h GemmArgsT::epi, bit 2 only; lower square output, every tile on the stream-K
   // schedule).  Tile norms: a tile finished by one workgroup leaves its sum of squares in sumsq[idx], idx =
   // ti (ti + 1) / 2 + tj; a split tile is finished by the 32 bands of the fix-up kernel, which leave theirs in
   // sumsq[nt_all + 32 idx + band].  The other entries of a tile are written as zero, so the sum over all
@@ -108,14 +108,8 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_streamk_kernel(SkParams<
         R* c = C + (int64_t)row * ldc + col;
         R o = alpha * v;
         if (beta != (R)0) o += beta * (*c);
-        if (EPI & 1) {
-          // the diagonal tile's strict upper part comes from the transposed store of its lower part
-          if (row >= col) *c = o;
-          if (row > col) C[(int64_t)col * ldc + row] = o;
-        } else {
-          *c = o;
-        }
-        if (EPI & 2) ss += (double)o * (double)o;
+        *c = o;
+        ss += (double)o * (double)o;
       });
       if (EPI & 2) {
 #pragma unroll
@@ -187,18 +181,7 @@ __global__ __launch_bounds__(256) void streamk_fixup_kernel(SkParams<R> p, const
     for (; s < s1; ++s) sum += *reinterpret_cast<const V*>(p.partial + (int64_t)fix_slot[s] * (TILE * TILE) + off);
     V* cp = reinterpret_cast<V*>(p.C + (int64_t)(tl.row0 + r) * p.ldc + tl.col0 + c);
     const V val = (beta == (R)0) ? alpha * sum : alpha * sum + beta * (*cp);
-    if constexpr ((EPI & 1) != 0) {
-      // mirrored store (as the data-parallel epilogue: the lower part is the one that counts on a diagonal tile)
-      const int grow = tl.row0 + r;
-#pragma unroll
-      for (int q = 0; q < EPC; ++q) {
-        const int gcol = tl.col0 + c + q;
-        if (grow >= gcol) p.C[(int64_t)grow * p.ldc + gcol] = val[q];
-        if (grow > gcol) p.C[(int64_t)gcol * p.ldc + grow] = val[q];
-      }
-    } else {
-      *cp = val;
-    }
+    *cp = val;
     if constexpr ((EPI & 2) != 0) {
 #pragma unroll
       for (int q = 0; q < EPC; ++q) ss += (double)val[q] * (double)val[q];
@@ -340,16 +323,16 @@ bool gemm_streamk_applies(const GemmArgsT<R>& a) { return streamk_first_tile(a) 
 template bool gemm_streamk_applies<double>(const GemmArgsT<double>&);
 template bool gemm_streamk_applies<float>(const GemmArgsT<float>&);
 
-// Fused epilogues on the stream-K schedule: mirror (1) and tile norms (2) of a square lower output whose tiles ALL
-// take the stream-K schedule (the launches with operands triangular on both sides: T = L^-1 L_V and Q = I - T T^T
-// of a unit below the size where the XCD-aware tables take over), in the operand layouts the fit uses.
+// Fused epilogue on the stream-K schedule: the tile norms (2) of a square lower output whose tiles ALL take the
+// stream-K schedule (T = L^-1 L_V of a unit below the size where the XCD-aware tables take over).  The mirrored
+// store (1) was built for this schedule too and taken out again: the transposed stores of an accumulator tile are
+// 32-byte fragments, which cost Q's launch 50 us and its fix-up 16 at N = 4096 against 28 us for the separate
+// symmetrisation pass (which transposes through LDS).
 template <typename R>
 bool gemm_streamk_carries(const GemmArgsT<R>& a) {
   if (streamk_first_tile(a) != 0) return false;
   if (!a.out_lower || a.M != a.N || a.a_kmajor) return false;
-  if (a.epi == 2) return a.b_kmajor && a.sumsq != nullptr;
-  if (a.epi == 1) return !a.b_kmajor;
-  return false;
+  return a.epi == 2 && a.b_kmajor && a.sumsq != nullptr;
 }
 template bool gemm_streamk_carries<double>(const GemmArgsT<double>&);
 template bool gemm_streamk_carries<float>(const GemmArgsT<float>&);
@@ -411,14 +394,6 @@ int launch_gemm_streamk(const GemmArgsT<R>& a, hipStream_t s) {
     hipLaunchKernelGGL((gemm_streamk_kernel<R, false, true, 2>), grid, block, 0, s, p);
     if (plan.nfix)
       hipLaunchKernelGGL((streamk_fixup_kernel<R, 2>), dim3(plan.nfix, 32), dim3(256), 0, s, p, plan.fix_tile, plan.fix_ptr,
-                         plan.fix_slot);
-    GP_HIP(hipGetLastError());
-    return 0;
-  }
-  if (a.epi == 1) {
-    hipLaunchKernelGGL((gemm_streamk_kernel<R, false, false, 1>), grid, block, 0, s, p);
-    if (plan.nfix)
-      hipLaunchKernelGGL((streamk_fixup_kernel<R, 1>), dim3(plan.nfix, 32), dim3(256), 0, s, p, plan.fix_tile, plan.fix_ptr,
                          plan.fix_slot);
     GP_HIP(hipGetLastError());
     return 0;
