@@ -232,3 +232,37 @@ def test_lockstep_and_free_running_schedules_give_the_same_bits():
         assert p.returncode == 0, p.stderr[-2000:]
         outs.append([l for l in p.stdout.splitlines() if l.startswith("HEX")][0])
     assert outs[0] == outs[1] == outs[2], outs
+
+
+_CHILD_SK = r"""
+import sys, torch
+sys.path.insert(0, %r)
+from gaussian_processes_amd import synthetic as syn
+from gaussian_processes_amd.engine import GPFitEngine
+import bench
+N, d = 3712, 64                       # 29 x 30 / 2 = 435 lower 128-tiles: T takes the stream-K schedule
+dev = torch.device("cuda:0")
+grid = syn.grid_for(d); lower, upper = syn.limits()
+X = torch.from_numpy(syn.stimuli(N, d)).to(dev)
+r_np, m_np = syn.cell_inputs(N, 1)
+V = bench.build_V(X, grid, syn.theta0(1), dev)
+eng = GPFitEngine(N, d)
+o = eng.fit_eval(syn.theta_eval(1), lower, upper, grid, X, torch.from_numpy(r_np).to(dev), torch.from_numpy(m_np).to(dev), V,
+                 syn.F_PARAMS["logA"], syn.F_PARAMS["lambda0"], want_vectors=False)
+print("VAL", repr(float(o["tr_KinvV"])), repr(float(o["loss"])), " ".join(repr(float(v)) for v in o["grad"].values()))
+"""
+
+
+def test_tile_norms_on_the_stream_k_schedule_match_the_separate_pass():
+    """tr(K~^-1 V) = ||T||_F^2 at a size where T = L^-1 L_V takes the stream-K schedule: the tile norms left behind
+    by the launch and its fix-up kernel (33 table entries per tile, gemm_sumsq_entries) against the separate pass over
+    T (GPFIT_FUSED_EPI=0) -- two processes, the switch is read once.  Same T, two summation orders of N^2 / 2 squares."""
+    vals = []
+    for extra in ({}, {"GPFIT_FUSED_EPI": "0"}):
+        p = subprocess.run([sys.executable, "-c", _CHILD_SK % ROOT], env=dict(os.environ, **extra), capture_output=True, text=True, timeout=300)
+        assert p.returncode == 0, p.stderr[-2000:]
+        vals.append([float(x) for x in [l for l in p.stdout.splitlines() if l.startswith("VAL")][0].split()[1:]])
+    fused, separate = np.array(vals[0]), np.array(vals[1])
+    assert abs(fused[0] - separate[0]) <= 1e-13 * abs(separate[0]), (fused[0], separate[0])      # the trace term itself
+    assert abs(fused[1] - separate[1]) <= 1e-13 * abs(separate[1])                                # the loss it enters
+    assert np.abs(fused[2:] - separate[2:]).max() <= 1e-11 * np.abs(separate[2:]).max()           # gradients: Q's passes differ too
