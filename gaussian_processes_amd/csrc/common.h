@@ -105,6 +105,13 @@ template <typename R> int gemm_pick_tile(const GemmArgsT<R>& a);   // block tile
 // stream-K schedule for large 128-tile launches (gemm_streamk.hip): 0 issued, 1 not applicable
 template <typename R> int launch_gemm_streamk(const GemmArgsT<R>& a, hipStream_t s);
 template <typename R> int launch_gemm_plain(const GemmArgsT<R>& a, hipStream_t s);  // data-parallel launch, no stream-K
+// Two independent pointer-batched products as ONE launch (blockIdx.z picks the problem): small-tile products of the
+// latency-bound levels of the recursion that depend on the same predecessor but differ in structure (lower output or
+// not, operand layout, alpha / beta), so they cannot share a pointer batch.  gemm_pair_ok: both are plain pointer
+// batches on full 32-tiles with a row-major op(A); the launch then runs exactly the tile bodies the two separate
+// launches would have run (same bits).
+template <typename R> bool gemm_pair_ok(const GemmArgsT<R>& a, const GemmArgsT<R>& b);
+template <typename R> int launch_gemm_pair(const GemmArgsT<R>& a, const GemmArgsT<R>& b, hipStream_t s);
 // XCD-aware data-parallel schedule (gemm_sched.hip): 0 issued, 1 not applicable.  Walk bit 3 asks for it.
 template <typename R> int launch_gemm_xcd(const GemmArgsT<R>& a, hipStream_t s);
 // would launch_gemm run these arguments on a data-parallel schedule (plain or XCD-aware), i.e. honour a.epi?

@@ -237,13 +237,29 @@ int potrf_rec(const CholBufsT<R>& B, int r0, int n, int need_inv, hipStream_t s)
     GP_TRY(gemm<R>(side, 0, 1, n2, n1, n1, 1.0, at(B.L, r1, r0), ld, at(B.Li, r0, r0), ld, 0.0, at(B.Tmp, r1, r0), ld, 0, 0, 1, walks()[1], 2 + B.chain, c->sk_ws[2 + B.chain], false, (B.half_occ >> 1) & 1));
     GP_HIP(hipEventRecord(joined, side));
   }
-  // A22 -= L21 L21^T          (syrk, lower tiles only)
-  GP_TRY(gemm<R>(s, 0, 0, n2, n2, n1, -1.0, at(B.L, r1, r0), ld, at(B.L, r1, r0), ld, 1.0, at(B.A, r1, r1), ld, 1, 0, 0, 0, B.ws, B.sk_ws, false, B.half_occ & 1));
+  // A22 -= L21 L21^T          (syrk, lower tiles only); on the latency-bound levels tmp = L21 * Li11 shares its launch
+  // (potrf_lockstep below does the same: the two routes stay launch-for-launch the same products)
+  bool merged = false;
+  if (need_inv == 1 && !joined && !(B.half_occ & 1)) {
+    static const bool no_batch = getenv("GPFIT_NO_BATCH") != nullptr;
+    auto one = [&](GemmArgsT<R> g) { g.nptr = 1; g.batch = 1; g.Ap[0] = g.A; g.Bp[0] = g.B; g.Cp[0] = g.C; return g; };
+    const GemmArgsT<R> g2 = one(gemm_args<R>(0, 0, n2, n2, n1, -1.0, at(B.L, r1, r0), ld, at(B.L, r1, r0), ld, 1.0, at(B.A, r1, r1), ld,
+                                             1, 0, 0, 0, B.ws, B.sk_ws));
+    const GemmArgsT<R> g3 = one(gemm_args<R>(0, 1, n2, n1, n1, 1.0, at(B.L, r1, r0), ld, at(B.Li, r0, r0), ld, 0.0, at(B.Tmp, r1, r0), ld,
+                                             0, 0, 1, walks()[1], B.ws, B.sk_ws));
+    if (!no_batch && gemm_pair_ok(g2, g3)) {
+      ProfScope ps(s, g_prof ? gemm_flops(g2) + gemm_flops(g3) : 0.0, 3);
+      GP_TRY(launch_gemm_pair(g2, g3, s));
+      merged = true;
+    }
+  }
+  if (!merged)
+    GP_TRY(gemm<R>(s, 0, 0, n2, n2, n1, -1.0, at(B.L, r1, r0), ld, at(B.L, r1, r0), ld, 1.0, at(B.A, r1, r1), ld, 1, 0, 0, 0, B.ws, B.sk_ws, false, B.half_occ & 1));
   GP_TRY(potrf_rec<R>(B, r1, n2, need_inv ? 1 : 0, s));
   if (need_inv == 1) {
     // Li21 = -Li22 * (L21 * Li11)
     if (joined) GP_HIP(hipStreamWaitEvent(s, joined, 0));
-    else GP_TRY(gemm<R>(s, 0, 1, n2, n1, n1, 1.0, at(B.L, r1, r0), ld, at(B.Li, r0, r0), ld, 0.0, at(B.Tmp, r1, r0), ld, 0, 0, 1, walks()[1], B.ws, B.sk_ws, false, B.half_occ & 1));
+    else if (!merged) GP_TRY(gemm<R>(s, 0, 1, n2, n1, n1, 1.0, at(B.L, r1, r0), ld, at(B.Li, r0, r0), ld, 0.0, at(B.Tmp, r1, r0), ld, 0, 0, 1, walks()[1], B.ws, B.sk_ws, false, B.half_occ & 1));
     GP_TRY(gemm<R>(s, 0, 1, n2, n1, n2, -1.0, at(B.Li, r1, r1), ld, at(B.Tmp, r1, r0), ld, 0.0, at(B.Li, r1, r0), ld, 0, 1, 0, walks()[2], B.ws, B.sk_ws, false, B.half_occ & 1));
   }
   return 0;
@@ -342,6 +358,25 @@ static int bgemm(const CholBatchT<R>& B, hipStream_t s, uint32_t mask, int a_kma
                       b_tri, reverse, ws_id, sk_ws);
 }
 
+// the pointer batch of the chains in `mask` (as bgemm builds it), for launches that take two batches at once
+template <typename R>
+static GemmArgsT<R> batch_args(const CholBatchT<R>& B, uint32_t mask, int a_kmajor, int b_kmajor, int M, int N, int K, double alpha,
+                               R* const* Ab, int64_t offA, R* const* Bb, int64_t offB, double beta, R* const* Cb, int64_t offC,
+                               int out_lower, int a_tri, int b_tri, int reverse) {
+  GemmArgsT<R> g = gemm_args<R>(a_kmajor, b_kmajor, M, N, K, alpha, (const R*)nullptr, B.ld, (const R*)nullptr, B.ld, beta,
+                                (R*)nullptr, B.ld, out_lower, a_tri, b_tri, reverse, B.ws, B.sk_ws);
+  int cnt = 0;
+  for (int b = 0; b < B.nb; ++b)
+    if (mask & (1u << b)) {
+      g.Ap[cnt] = Ab[b] + offA; g.Bp[cnt] = Bb[b] + offB; g.Cp[cnt] = Cb[b] + offC;
+      ++cnt;
+    }
+  g.nptr = cnt;
+  g.batch = cnt;
+  if (cnt > 0) { g.A = g.Ap[0]; g.B = g.Bp[0]; g.C = g.Cp[0]; }
+  return g;
+}
+
 template <typename R>
 int potrf_lockstep(const CholBatchT<R>& B, int r0, int n, uint32_t need, hipStream_t s) {
   const int64_t ld = B.ld;
@@ -389,14 +424,33 @@ int potrf_lockstep(const CholBatchT<R>& B, int r0, int n, uint32_t need, hipStre
                     walks()[1], 2 + B.chain, c->sk_ws[2 + B.chain]));
     GP_HIP(hipEventRecord(joined, side));
   }
-  // A22 -= L21 L21^T
-  GP_TRY(bgemm<R>(B, s, all, 0, 0, n2, n2, n1, -1.0, B.L, off(r1, r0), B.L, off(r1, r0), 1.0, B.A, off(r1, r1), 1, 0, 0, 0,
-                  B.ws, B.sk_ws));
+  // A22 -= L21 L21^T.  On the latency-bound levels the first product of the inverse merge, L21 L11^-1 (it needs
+  // L21 and L11^-1 only), rides in the same launch: one launch boundary less per node of the recursion.
+  bool merged = false;
+  if (need && !joined) {
+    static const bool no_batch = getenv("GPFIT_NO_BATCH") != nullptr;
+    const GemmArgsT<R> g2 = batch_args<R>(B, all, 0, 0, n2, n2, n1, -1.0, B.L, off(r1, r0), B.L, off(r1, r0), 1.0, B.A, off(r1, r1),
+                                          1, 0, 0, 0);
+    const GemmArgsT<R> g3 = batch_args<R>(B, need, 0, 1, n2, n1, n1, 1.0, B.L, off(r1, r0), B.Li, off(r0, r0), 0.0, B.Tmp,
+                                          off(r1, r0), 0, 0, 1, walks()[1]);
+    if (!no_batch && gemm_pair_ok(g2, g3)) {
+      if (gemm_log_eval() >= 0 && g_eval_count == gemm_log_eval())
+        fprintf(stderr, "[gpfit gemm] pair: M %d N %d K %d lower 1 nb %d + M %d N %d K %d btri 1 nb %d tile %d flops %.6e\n", g2.M, g2.N,
+                g2.K, g2.nptr, g3.M, g3.N, g3.K, g3.nptr, gemm_pick_tile(g3), gemm_flops(g2) + gemm_flops(g3));
+      ProfScope ps(s, g_prof ? gemm_flops(g2) + gemm_flops(g3) : 0.0, 3);
+      GP_TRY(launch_gemm_pair(g2, g3, s));
+      merged = true;
+    }
+  }
+  if (!merged)
+    GP_TRY(bgemm<R>(B, s, all, 0, 0, n2, n2, n1, -1.0, B.L, off(r1, r0), B.L, off(r1, r0), 1.0, B.A, off(r1, r1), 1, 0, 0, 0,
+                    B.ws, B.sk_ws));
   GP_TRY(potrf_lockstep<R>(B, r1, n2, need, s));
   if (need) {
     if (joined) GP_HIP(hipStreamWaitEvent(s, joined, 0));
-    else GP_TRY(bgemm<R>(B, s, need, 0, 1, n2, n1, n1, 1.0, B.L, off(r1, r0), B.Li, off(r0, r0), 0.0, B.Tmp, off(r1, r0), 0, 0,
-                         1, walks()[1], B.ws, B.sk_ws));
+    else if (!merged)
+      GP_TRY(bgemm<R>(B, s, need, 0, 1, n2, n1, n1, 1.0, B.L, off(r1, r0), B.Li, off(r0, r0), 0.0, B.Tmp, off(r1, r0), 0, 0,
+                      1, walks()[1], B.ws, B.sk_ws));
     GP_TRY(bgemm<R>(B, s, need, 0, 1, n2, n1, n2, -1.0, B.Li, off(r1, r1), B.Tmp, off(r1, r0), 0.0, B.Li, off(r1, r0), 0, 1, 0,
                     walks()[2], B.ws, B.sk_ws));
   }

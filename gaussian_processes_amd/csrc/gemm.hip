@@ -381,6 +381,80 @@ int launch_gemm_plain(const GemmArgsT<R>& a, hipStream_t s) {
   return 0;
 }
 
+// ---- two structurally different small-tile pointer batches in one launch (common.h: launch_gemm_pair)
+template <typename R>
+struct GemmPairT {
+  GemmArgsT<R> g[2];
+  int tiles[2], tiles_n[2];
+};
+
+template <typename R, int T, int NS>
+__global__ __launch_bounds__(GEMM_THREADS, (NS > 2 ? 2 : 4)) void gemm_pair_kernel(GemmPairT<R> q) {
+  __shared__ __attribute__((aligned(16))) R smem[2 * NS * Real<R>::KT * T];
+  const int w = blockIdx.z;
+  const GemmArgsT<R>& p = q.g[w];
+  if ((int)blockIdx.x >= q.tiles[w] || (int)blockIdx.y >= p.batch) return;
+  if (p.b_kmajor) gemm_tile_body<R, false, true, false, T, NS>(p, q.tiles_n[w], q.tiles[w], smem);
+  else gemm_tile_body<R, false, false, false, T, NS>(p, q.tiles_n[w], q.tiles[w], smem);
+}
+
+// the block tile both members would take on their own (32 or 64), 0: not a member of a pair
+template <typename R>
+static int pair_member_tile(const GemmArgsT<R>& a) {
+  constexpr int EPC = 16 / (int)sizeof(R);
+  if (a.nptr <= 0 || a.nptr > GEMM_MAXB || a.epi || a.split_k > 1 || a.sched || a.half_occ || a.tile_limit || a.a_kmajor) return 0;
+  if (a.M <= 0 || a.N <= 0 || (a.M % 64) || (a.N % 64) || (a.out_lower && ((a.M % TILE) || a.M != a.N))) return 0;
+  if (a.K % ktile_of<R>() != 0 || (a.lda % EPC) || (a.ldb % EPC)) return 0;
+  const int T = gemm_pick_tile(a);
+  return (T == 32 || T == 64) ? T : 0;
+}
+
+template <typename R>
+bool gemm_pair_ok(const GemmArgsT<R>& a, const GemmArgsT<R>& b) {
+  static const bool off = getenv("GPFIT_NO_PAIR") != nullptr;   // tuning knob: the two launches on their own
+  static const bool no64 = getenv("GPFIT_NO_PAIR64") != nullptr;
+  if (off) return false;
+  const int ta = pair_member_tile(a), tb = pair_member_tile(b);
+  return ta != 0 && ta == tb && !(no64 && ta == 64);
+}
+template bool gemm_pair_ok<double>(const GemmArgsT<double>&, const GemmArgsT<double>&);
+template bool gemm_pair_ok<float>(const GemmArgsT<float>&, const GemmArgsT<float>&);
+
+template <typename R>
+int launch_gemm_pair(const GemmArgsT<R>& a, const GemmArgsT<R>& b, hipStream_t s) {
+  if (!gemm_pair_ok(a, b)) {
+    set_error("launch_gemm_pair: the two problems cannot share a launch (ask gemm_pair_ok first)");
+    return -3;
+  }
+  static_assert(sizeof(GemmPairT<R>) <= 4096, "kernel arguments are limited to 4 KiB");
+  const int T = pair_member_tile(a);
+  GemmPairT<R> q;
+  int gx = 0, gy = 0;
+  long total = 0;
+  for (int w = 0; w < 2; ++w) {
+    q.g[w] = w == 0 ? a : b;
+    GemmArgsT<R>& p = q.g[w];
+    p.batch = p.nptr;
+    const int tm = p.M / T, tn = p.N / T;
+    q.tiles_n[w] = tn;
+    q.tiles[w] = p.out_lower ? lower_tile_count(p.M / TILE, TILE / T) : tm * tn;
+    gx = std::max(gx, q.tiles[w]);
+    gy = std::max(gy, p.batch);
+    total += (long)q.tiles[w] * p.batch;
+  }
+  const dim3 grid(gx, gy, 2), block(GEMM_THREADS);
+  // stages as launch_T picks them: the deep pipeline when the launch has at most two workgroups per CU
+  static const int deep_max = getenv("GPFIT_DEEP_MAX") ? atoi(getenv("GPFIT_DEEP_MAX")) : 512;
+  if (T == 32 && total <= deep_max) hipLaunchKernelGGL((gemm_pair_kernel<R, 32, 8>), grid, block, 0, s, q);
+  else if (T == 32) hipLaunchKernelGGL((gemm_pair_kernel<R, 32, 2>), grid, block, 0, s, q);
+  else if (total <= deep_max) hipLaunchKernelGGL((gemm_pair_kernel<R, 64, 4>), grid, block, 0, s, q);
+  else hipLaunchKernelGGL((gemm_pair_kernel<R, 64, 2>), grid, block, 0, s, q);
+  GP_HIP(hipGetLastError());
+  return 0;
+}
+template int launch_gemm_pair<double>(const GemmArgsT<double>&, const GemmArgsT<double>&, hipStream_t);
+template int launch_gemm_pair<float>(const GemmArgsT<float>&, const GemmArgsT<float>&, hipStream_t);
+
 template int launch_gemm<double>(const GemmArgsT<double>&, hipStream_t);
 template int launch_gemm<float>(const GemmArgsT<float>&, hipStream_t);
 template int launch_gemm_plain<double>(const GemmArgsT<double>&, hipStream_t);
