@@ -12,6 +12,13 @@ for line in open(log):
         v = list(m.groups())
         launches.append(dict(M=int(v[0]), N=int(v[1]), K=int(v[2]), atri=int(v[3]), btri=int(v[4]), lower=int(v[5]), nb=int(v[6]),
                              tile=int(v[7]), flops=float(v[11]), epi=int(v[10])))
+        continue
+    # a paired launch (gemm_pair_kernel): the update of a node and the first product of its inverse merge in one kernel
+    m = re.search(r"\[gpfit gemm\] pair: M (\d+) N (\d+) K (\d+) lower 1 nb (\d+) \+ M (\d+) N (\d+) K (\d+) btri 1 nb (\d+) tile (\d+) flops (\S+)", line)
+    if m:
+        v = list(m.groups())
+        launches.append(dict(M=int(v[0]), N=int(v[1]), K=int(v[2]), atri=0, btri=0, lower=1, nb=int(v[3]) + int(v[7]), tile=int(v[8]),
+                             flops=float(v[9]), epi=0))
 t = list(csv.DictReader(open(trace)))
 for r in t:
     r['s'] = int(r['Start_Timestamp']); r['e'] = int(r['End_Timestamp'])
@@ -21,7 +28,7 @@ starts = [i for i, r in enumerate(t) if 'localker_kernel' in r['Kernel_Name']]
 evals = [i for i in starts if any('gram_acos' in x['Kernel_Name'] for x in t[i:i + 8])]
 lo = evals[k - 1]; hi = evals[k] if k < len(evals) else len(t)
 fit = t[lo:hi]
-gemms = [r for r in fit if ('gemm_mfma' in r['Kernel_Name'] or 'gemm_epi' in r['Kernel_Name'] or 'gemm_xcd' in r['Kernel_Name']
+gemms = [r for r in fit if ('gemm_mfma' in r['Kernel_Name'] or 'gemm_epi' in r['Kernel_Name'] or 'gemm_xcd' in r['Kernel_Name'] or 'gemm_pair' in r['Kernel_Name']
                            or 'gemm_streamk_kernel' in r['Kernel_Name'])]
 # a uniform launch with a stream-K tail is two kernels (head + tail): merge a streamk kernel into the preceding head when the log has one entry
 out = []
