@@ -222,16 +222,18 @@ print("HEX", float(o["loss"]).hex(), " ".join(float(v).hex() for v in o["grad"].
 
 
 def test_lockstep_and_free_running_schedules_give_the_same_bits():
-    """The single unit under the three schedules of the factorisations -- lock step with shared launches (default),
-    lock step with every product launched on its own (GPFIT_NO_BATCH), the two free-running chains of rounds 1-2
-    (GPFIT_LOCKSTEP=0) -- in three processes, one after the other (the switches are read once per process)."""
+    """The single unit under the schedules of the factorisations -- lock step with shared and paired launches
+    (default), without the paired launches (GPFIT_NO_PAIR: the update of a node and the first product of its inverse
+    merge as two launches), with every product launched on its own (GPFIT_NO_BATCH), the two free-running chains of
+    rounds 1-2 (GPFIT_LOCKSTEP=0, with and without its own paired launches) -- one process each (the switches are read
+    once per process)."""
     outs = []
-    for extra in ({}, {"GPFIT_NO_BATCH": "1"}, {"GPFIT_LOCKSTEP": "0"}):
+    for extra in ({}, {"GPFIT_NO_PAIR": "1"}, {"GPFIT_NO_BATCH": "1"}, {"GPFIT_LOCKSTEP": "0"}, {"GPFIT_LOCKSTEP": "0", "GPFIT_NO_PAIR": "1"}):
         env = dict(os.environ, **extra)
         p = subprocess.run([sys.executable, "-c", _CHILD % ROOT], env=env, capture_output=True, text=True, timeout=300)
         assert p.returncode == 0, p.stderr[-2000:]
         outs.append([l for l in p.stdout.splitlines() if l.startswith("HEX")][0])
-    assert outs[0] == outs[1] == outs[2], outs
+    assert all(o == outs[0] for o in outs), outs
 
 
 _CHILD_SK = r"""
