@@ -112,6 +112,17 @@ def profiled_mfma_util(kernel_name):
 PROFILED_EVALUATIONS = 5   # evaluations behind the live per-launch figures of `roofline` (HIP events around every GEMM launch)
 
 
+def clamp_groups(args, n_local):
+    """A rank never allocates contexts it cannot fill: the group size is clamped to the rank's local unit count and the
+    number of engine sets to the number of groups that leaves (at --gpus 8, cells64 gives every rank 8 cells: ONE group
+    of 8 on 8 contexts, not a half-full group of 16 on 32 contexts = 56 GB).  Every rank holds the same count up to one
+    unit (cyclic partition), and the clamp only ever shrinks, so results do not change: a unit's numbers do not depend
+    on the group it is evaluated in."""
+    if args.group > 0:
+        args.group = max(1, min(args.group, n_local))
+        args.sets = max(1, min(args.sets, -(-max(1, n_local) // args.group)))
+
+
 def build_V(X, grid, th0, dev):
     """V = K~(theta0)/2 (SPD by construction).  Setup only, outside the timed
     region; uses the library's own kernel-build entry point."""
@@ -327,6 +338,7 @@ def main():
         args.group = {"cells64": 16, "thetagrid": 16}.get(args.config, 0)   # thetagrid: 16 contexts of N = 8192 are 118 GB
     if args.sets is None:
         args.sets = 2 if args.config == "cells64" else 1
+    args.group_asked, args.sets_asked = args.group, args.sets
     dtype_name = args.dtype or ("mixed" if args.config == "thetagrid" else "f64")
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -419,6 +431,7 @@ def main():
             rc, mc = syn.cell_inputs(N, c)
             inputs[c] = (torch.from_numpy(rc).to(dev), torch.from_numpy(mc).to(dev), build_V(X, grid, syn.theta0(c), dev),
                          syn.theta_eval(c))
+        clamp_groups(args, len(mine))
         n_eng = max(1, args.group) * max(1, args.sets) if args.group > 0 else max(1, args.depth)
         engs = [eng] + [GPFitEngine(N, d, device=local_rank) for _ in range(n_eng - 1)]
         extra_engines = engs[1:]
@@ -484,6 +497,7 @@ def main():
         # point's latency-bound Cholesky chain runs beside another's large gradient products (each context
         # factors V once and then reuses its own copy of the factor)
         tdepth = max(1, args.depth)
+        clamp_groups(args, len(mine))
         n_eng = max(1, args.group) * max(1, args.sets) if args.group > 0 else tdepth
         engs = [eng] + [GPFitEngine(N, d, device=local_rank) for _ in range(n_eng - 1)]
         extra_engines = engs[1:]
@@ -742,7 +756,11 @@ def main():
             "dtype": {"f64": "f64", "f32": "f32", "mixed": "f64 (kernel build, Cholesky, loss) + f32 (gradient products)"}[dtype_name],
             "data": "synthetic",
             "config": {"workload": workload, "N": N, "d": d, "units_per_step": units_per_step,
-                       "parallelism": f"independent units over {world} GPU(s), one process per GPU, no data-path collective"},
+                       "parallelism": f"independent units over {world} GPU(s), one process per GPU, no data-path collective"
+                                      + (f"; rank 0 holds {len(mine)} of {units_per_step} units: groups of {args.group} on "
+                                         f"{args.sets} set(s) of contexts (asked for: {args.group_asked} x {args.sets_asked}, "
+                                         "clamped to the local share)"
+                                         if args.config in ("cells64", "thetagrid") and args.group > 0 else "")},
             "loss": res["loss"],
             "roofline": roofline,
         }

@@ -330,7 +330,7 @@ int launch_chol_leaf(const R* A, int64_t lda, R* L, int64_t ldl, R* Linv, int64_
     if (device >= 0 && device < 64) attr_set[device].store(true, std::memory_order_release);
   }
 #ifdef GPFIT_DEV
-  static int dbg = -1;  // phase-ablation switch for scripts/dev_leaf.py (timing only; wrong results)
+  static int dbg = -1;  // phase-ablation switch for scripts/scratch/dev_leaf.py (timing only; wrong results)
   if (dbg < 0) dbg = getenv("GPFIT_LEAF_DBG") ? atoi(getenv("GPFIT_LEAF_DBG")) : 0;
 #else
   constexpr int dbg = 0;

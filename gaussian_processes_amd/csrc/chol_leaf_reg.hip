@@ -40,7 +40,7 @@
 
 namespace gpfit {
 
-// scripts/dev_leaf_time.hip defines GPFIT_LEAF_STAMPS and includes this file: shader-clock stamps of
+// scripts/scratch/dev_leaf_time.hip defines GPFIT_LEAF_STAMPS and includes this file: shader-clock stamps of
 // wave `owner` / wave 0 at the phase boundaries of every panel (never compiled into the library)
 #ifdef GPFIT_LEAF_STAMPS
 __device__ long long g_leaf_stamps[9 * 8];

@@ -1575,19 +1575,23 @@ static int fit_eval_sparse_impl(gpfit_ctx* c, void* stream, const double* theta,
   GP_TRY(launch_symmetrize_avg(S4, lb, nk, s));
   GP_TRY(launch_pack_lower(S4, lb, nk, S1, lb, nb, s));
   {
-    // K~_b = L L^T with L^-1 and V_b = L_V L_V^T (log|V_b|, :1326) in lock step; the V_b chain lives in four
-    // nb x nb slots of Wbuf, which nothing else needs between the projections above and P2 below
-    double* Vw = c->Wbuf;
+    // K~_b = L L^T with L^-1 and V_b = L_V L_V^T (log|V_b|, :1326) in lock step.  The V_b chain takes four work
+    // matrices that are dead between the projections above and the adjoints below, each of the context's full
+    // np_cap^2 size (nb <= np2 <= np_cap: an nb x nb chain fits whatever n_kept is): Wbuf (free until P2), Kbuf
+    // and Lbuf (K~ and K are consumed by the projections; rewritten as G_a and G_a K~_b^-1 further down) and Abuf
+    // (a V_b is formed behind the chain).  The cosine matrices in Cos / Libuf stay untouched.
+    double *Va = c->Wbuf, *Vl = c->Kbuf, *Vli = c->Lbuf, *Vt = c->Abuf;
     const int64_t slot = (int64_t)nb * nb;
-    GP_TRY(launch_pack_lower(V_b, ldvb, nk, Vw, lb, nb, s));
+    GP_TRY(launch_pack_lower(V_b, ldvb, nk, Va, lb, nb, s));
     CholBatchT<R> cb;
     cb.nb = 2;
     cb.A[0] = S1; cb.L[0] = S2; cb.Li[0] = S3; cb.Tmp[0] = S4; cb.info[0] = c->info + 0;
-    cb.A[1] = Vw; cb.L[1] = Vw + slot; cb.Li[1] = Vw + 2 * slot; cb.Tmp[1] = Vw + 3 * slot; cb.info[1] = c->info + 1;
+    cb.A[1] = Va; cb.L[1] = Vl; cb.Li[1] = Vli; cb.Tmp[1] = Vt; cb.info[1] = c->info + 1;
     cb.ld = lb; cb.ws = 0; cb.sk_ws = c->sk_ws[0]; cb.ctx = nullptr; cb.side_min = 0;
-    GP_HIP(hipMemsetAsync(Vw + slot, 0, (size_t)(3 * slot) * sizeof(double), s));   // tiles above the diagonal read as zero
+    for (double* p : {Vl, Vli, Vt})   // tiles above the diagonal read as zero
+      GP_HIP(hipMemsetAsync(p, 0, (size_t)slot * sizeof(double), s));
     GP_TRY(potrf_lockstep<R>(cb, 0, nb, 1u, s));
-    GP_TRY(launch_logdet(Vw + slot, lb, nk, c->scal + 40, s));
+    GP_TRY(launch_logdet(Vl, lb, nk, c->scal + 40, s));
   }
   GP_TRY(launch_logdet(S2, lb, nk, c->scal + 3, s));
   GP_TRY(gemm<R>(s, 1, 1, nb, nb, nb, 1.0, S3, lb, S3, lb, 0.0, S1, lb, 1, 2, 1));

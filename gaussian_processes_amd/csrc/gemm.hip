@@ -168,7 +168,7 @@ __global__ __launch_bounds__(GEMM_THREADS, (T == 128 || NS > 2 ? 2 : 4)) void ge
 // (<R, false, false>), one launch each per evaluation, so a profiler's per-kernel row for this name
 // IS that launch.
 #ifdef GPFIT_CLOCK_STAMPS
-// Diagnostic build only (scripts/dev_gemm_clock.sh): shader cycles (s_memtime) and 100 MHz ticks
+// Diagnostic build only (scripts/scratch/dev_gemm_clock.sh): shader cycles (s_memtime) and 100 MHz ticks
 // (s_memrealtime) each workgroup of the last scheduled launch spent, [B_KMAJOR][block][2]; read back with
 // hipMemcpyFromSymbol by gpfit_dev_gemm_clock.  No output value depends on them.
 __device__ long long g_gemm_clock[2][4096][2];

@@ -252,7 +252,7 @@ template <int N> __device__ __forceinline__ void dma_wait_barrier() {
   asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory");
 }
 
-// ABL: ablation bits for scripts/dev_gemm_abl.hip only (1 no barrier, 2 no DMA in the loop);
+// ABL: ablation bits for scripts/scratch/dev_gemm_abl.hip only (1 no barrier, 2 no DMA in the loop);
 // product code uses 0.
 // NS = LDS stages (each one A tile + one B tile); the DMA runs NS-1 tiles ahead of the MFMAs.
 // NS = 2 for the 128-tile (two co-resident workgroups hide each other's latency); the small-tile

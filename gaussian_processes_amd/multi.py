@@ -22,9 +22,18 @@ def partition(n_units: int, world: int, rank: int) -> List[int]:
     return [u for u in range(n_units) if u % world == rank]
 
 
-def broadcast_stimuli(X: torch.Tensor | None, shape, device, src: int = 0) -> torch.Tensor:
+def _single(force_collectives: bool) -> bool:
+    """True when there is nothing to communicate: no process group, or a group of one rank -- unless the caller
+    asks for the collectives anyway (``force_collectives``: a world-size-1 ``nccl`` group on a one-GPU box then
+    runs exactly the RCCL calls of the multi-GPU job, which is how tests/test_gpu_rccl.py exercises them)."""
+    if not dist.is_initialized():
+        return True
+    return dist.get_world_size() == 1 and not force_collectives
+
+
+def broadcast_stimuli(X: torch.Tensor | None, shape, device, src: int = 0, force_collectives: bool = False) -> torch.Tensor:
     """Rank ``src`` passes X; every other rank passes None and receives a copy."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if _single(force_collectives):
         assert X is not None
         return X
     if dist.get_rank() != src:
@@ -35,7 +44,7 @@ def broadcast_stimuli(X: torch.Tensor | None, shape, device, src: int = 0) -> to
     return X
 
 
-def broadcast_state(r, m, V, n: int, device, dtype=torch.float64, src: int = 0):
+def broadcast_state(r, m, V, n: int, device, dtype=torch.float64, src: int = 0, force_collectives: bool = False):
     """Per-cell state shared by every unit of a hyperparameter grid (BASELINE configs[4]: 512 theta
     points, one cell): ``r``, ``m`` (n each) and ``V`` (n x n) from rank ``src`` to all ranks.
 
@@ -44,7 +53,7 @@ def broadcast_state(r, m, V, n: int, device, dtype=torch.float64, src: int = 0):
     bound by one ~153 GB/s link; instead rank ``src`` SCATTERS ``world`` row blocks (each of its
     seven links carries 1/world of the payload) and the ranks ALL-GATHER them (every link carries
     one block in each direction): SURVEY.md section 5 / 8(e).  Ranks other than ``src`` pass None."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if _single(force_collectives):
         assert r is not None and m is not None and V is not None
         return r.to(device=device, dtype=dtype), m.to(device=device, dtype=dtype), V.to(device=device, dtype=dtype)
     world, rank = dist.get_world_size(), dist.get_rank()
@@ -133,27 +142,42 @@ def evaluate_units_grouped(units: Sequence[int], group_fn: Callable[[Sequence[in
         for j, row in enumerate(rows):
             table[g0 + j] = [float(v) for v in row]
 
-    pipelined = begin_fn is not None and finish_fn is not None and sets >= 2
+    split = begin_fn is not None and finish_fn is not None
+    if group_fn is None:
+        if not split:
+            raise ValueError("evaluate_units_grouped needs group_fn, or begin_fn together with finish_fn")
+        group_fn = lambda us: finish_fn(begin_fn(us, 0), 0)      # one set of engines: begin and collect back to back
+    pipelined = split and sets >= 2
     pending = None
-    for gi, g0 in enumerate(range(0, len(units), group)):
-        us = list(units[g0:g0 + group])
-        if not pipelined:
-            store(g0, len(us), group_fn(us))
-            continue
-        handle = begin_fn(us, gi % sets)
+    try:
+        for gi, g0 in enumerate(range(0, len(units), group)):
+            us = list(units[g0:g0 + group])
+            if not pipelined:
+                store(g0, len(us), group_fn(us))
+                continue
+            handle = begin_fn(us, gi % sets)
+            done, pending = pending, (handle, g0, len(us), gi % sets)
+            if done is not None:
+                store(done[1], done[2], finish_fn(done[0], done[3]))
         if pending is not None:
-            store(pending[1], pending[2], finish_fn(pending[0], pending[3]))
-        pending = (handle, g0, len(us), gi % sets)
-    if pending is not None:
-        store(pending[1], pending[2], finish_fn(pending[0], pending[3]))
+            done, pending = pending, None
+            store(done[1], done[2], finish_fn(done[0], done[3]))
+    finally:
+        # an exception above (begin_fn, finish_fn or a malformed result) must not leave a group enqueued: its
+        # contexts would refuse every later call ("an asynchronous evaluation is pending")
+        if pending is not None:
+            try:
+                finish_fn(pending[0], pending[3])
+            except Exception:
+                pass
     if not table:
         return torch.zeros((0, RESULT_WIDTH), dtype=torch.float64, device=device)
     return torch.tensor(table, dtype=torch.float64).to(device)
 
 
-def gather_results(local: torch.Tensor, n_units: int) -> torch.Tensor:
+def gather_results(local: torch.Tensor, n_units: int, force_collectives: bool = False) -> torch.Tensor:
     """All ranks receive the [n_units, 7] table in unit order."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if _single(force_collectives):
         return local
     world, rank = dist.get_world_size(), dist.get_rank()
     per = (n_units + world - 1) // world
@@ -170,7 +194,7 @@ def gather_results(local: torch.Tensor, n_units: int) -> torch.Tensor:
 
 def run_sharded(n_units: int, eval_fn: Callable[[int], Sequence[float]], device, submit_fn=None, collect_fn=None,
                 depth: int = 2, lockstep: bool = False, group_fn=None, group: int = 0, begin_fn=None, finish_fn=None,
-                sets: int = 1) -> torch.Tensor:
+                sets: int = 1, force_collectives: bool = False) -> torch.Tensor:
     """Evaluate all units, sharded cyclically over the ranks; with ``group_fn`` the local units go ``group`` at a
     time through one grouped call each (:func:`evaluate_units_grouped`; ``begin_fn`` / ``finish_fn`` / ``sets``: its
     pipelined form); with ``submit_fn`` / ``collect_fn`` they
@@ -184,4 +208,4 @@ def run_sharded(n_units: int, eval_fn: Callable[[int], Sequence[float]], device,
         local = evaluate_units_pipelined(mine, submit_fn, collect_fn, device, depth, lockstep)
     else:
         local = evaluate_units(mine, eval_fn, device)
-    return gather_results(local, n_units)
+    return gather_results(local, n_units, force_collectives)

@@ -1044,7 +1044,10 @@ def extend_inducing_set(fit_model, x_new, route=None):
     the grown matrix goes through ``_stabilised_basis`` like any other.
 
     Returns ``dict(xtilde=, m=, V=, init_kernel=)``; ``x_new`` is one image (any shape with the model's pixel
-    count).  The caller updates ``fit_parameters['ntilde']`` and passes the training data of its choice.
+    count).  The caller updates ``fit_parameters['ntilde']``.  PRECONDITION (the closed loop of the notebook, where
+    ``in_use_idx == xtilde_idx``): the refit's training set is the grown inducing set, ``x == xtilde`` -- the
+    ``init_kernel`` returned here carries ``K = K~`` and ``KKtilde_inv_b = B``, which is only the kernel of THAT
+    training set; ``varGP`` refuses it for any other (``init_kernel['square']``).
     ``route='eigh'`` forces the notebook's own step (eigendecomposition of the grown matrix), for A/B timing."""
     xt = _cu(fit_model['xtilde'])
     n, npx = xt.shape
@@ -1096,7 +1099,7 @@ def extend_inducing_set(fit_model, x_new, route=None):
         _BASIS.factor = None
     KB = K_new if route == 'identity' else matmul(K_new, B)
     init_kernel = {'C': C, 'mask': mask, 'K_tilde': K_new, 'K': K_new, 'Kvec': Kvec_new, 'B': B, 'K_tilde_b': K_b_, 'K_b': KB,
-                   'K_tilde_inv_b': K_inv_b, 'KKtilde_inv_b': B, 'basis_route': route, 'chol': chol}
+                   'K_tilde_inv_b': K_inv_b, 'KKtilde_inv_b': B, 'basis_route': route, 'chol': chol, 'square': True}
     return {'xtilde': xt_new, 'm': m_new, 'V': V_new, 'init_kernel': init_kernel}
 
 
@@ -1211,6 +1214,9 @@ def varGP(x, r, **kwargs):
         eigvecs, B, K_tilde_b, K_tilde_inv_b, K_b, KKtilde_inv_b = project(K_tilde, K)
     else:
         ik = kwargs['init_kernel']
+        if ik.get('square') and (ntilde != nt or tuple(ik['K'].shape) != (nt, ntilde)):
+            raise ValueError("varGP: this init_kernel was prepared by extend_inducing_set for a training set equal to the "
+                             f"grown inducing set ({tuple(ik['K'].shape)[0]} images); got n_t = {nt}, n_tilde = {ntilde}")
         C, mask, K_tilde, K, Kvec = _cu(ik['C']), ik['mask'].to(dev), _cu(ik['K_tilde']), _cu(ik['K']), _cu(ik['Kvec'])
         B, K_tilde_b, K_b, K_tilde_inv_b = _cu(ik['B']), _cu(ik['K_tilde_b']), _cu(ik['K_b']), _cu(ik['K_tilde_inv_b'])
         # an init_kernel prepared by extend_inducing_set says which route built its basis (and brings the factor of

@@ -43,7 +43,7 @@ python examples/one_cell_fit.py --n 4096 --d 256 >> $out/${tag}_whole_fits.log 2
 python examples/one_cell_fit.py --n 8192 --d 256 >> $out/${tag}_whole_fits.log 2>&1
 python examples/one_cell_fit.py --n 8192 --d 256 --tol 1e-14 >> $out/${tag}_whole_fits.log 2>&1
 GPFIT_FORCE_EIGH=1 python examples/one_cell_fit.py --n 8192 --d 256 --tol 1e-14 >> $out/${tag}_whole_fits.log 2>&1
-python scripts/dev_projected.py 4096 >> $out/${tag}_whole_fits.log 2>&1
+python scripts/scratch/dev_projected.py 4096 >> $out/${tag}_whole_fits.log 2>&1
 python scripts/whole_fit_breakdown.py 8192 256 $out/${tag}_whole_fit_breakdown.json > /dev/null 2>&1
 python examples/active_learning.py --pool 200 --start 40 --iterations 6 > $out/${tag}_active_loop.log 2>&1
 python examples/active_learning.py --pool 200 --start 40 --iterations 6 --notebook-step >> $out/${tag}_active_loop.log 2>&1

@@ -1,5 +1,5 @@
 // Dev harness: ablations of the fp64 GEMM main loop on a plain 8192^3 problem (not shipped).
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -Iinclude -Igaussian_processes_amd/csrc scripts/dev_gemm_abl.hip -o gpurun_tmp/abl
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -Iinclude -Igaussian_processes_amd/csrc scripts/scratch/dev_gemm_abl.hip -o gpurun_tmp/abl
 #include "gemm_core.h"
 #include <cmath>
 #include <cstdio>

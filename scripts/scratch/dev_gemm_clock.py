@@ -1,5 +1,5 @@
 """In-kernel shader clock of the dominant GEMM launches in the steady-state fit loop (diagnostic build,
-scripts/dev_gemm_clock.sh): >= 2 s of back-to-back fits on the bench inputs, then the s_memtime /
+scripts/scratch/dev_gemm_clock.sh): >= 2 s of back-to-back fits on the bench inputs, then the s_memtime /
 s_memrealtime stamps of the last T (B k-major) and Q launches -- median over workgroups -- beside the
 HIP-event duration of those launches.  MI355X_MICROARCH.md 'DVFS give-back' item 6."""
 import ctypes, os, sys, time

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Diagnostic build of the library with in-kernel clock stamps around the scheduled GEMM body
 # (gemm.hip, GPFIT_CLOCK_STAMPS), into gpurun_tmp/libgpfit_clk.so.  Run here; then on the box:
-#   python scripts/dev_gemm_clock.py
+#   python scripts/scratch/dev_gemm_clock.py
 set -e
 cd "$(dirname "$0")/.."
 python -m gaussian_processes_amd.build > /dev/null

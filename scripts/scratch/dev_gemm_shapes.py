@@ -1,5 +1,5 @@
 """Product GEMM entry point on the shapes of the fit's large launches, standalone (compare with
-scripts/dev_gemm_abl.hip and with the in-fit durations of the kernel trace)."""
+scripts/scratch/dev_gemm_abl.hip and with the in-fit durations of the kernel trace)."""
 import ctypes, os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -1,5 +1,5 @@
 """Groups of independent units in one call (gpfit_fit_eval_batch) against unit-by-unit and pipelined evaluation.
-    python scripts/dev_group.py [N] [d] [units] [group] [mode: f64|mixed] [reuse_V 0|1]"""
+    python scripts/scratch/dev_group.py [N] [d] [units] [group] [mode: f64|mixed] [reuse_V 0|1]"""
 import os, sys, time
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

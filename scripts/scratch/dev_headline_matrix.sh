@@ -1,6 +1,6 @@
 #!/bin/bash
 # Headline unit under the schedule / hardware-queue settings that matter (bench.py itself, so the streams are created
-# in the order the driver's run creates them): bash scripts/dev_headline_matrix.sh > gpurun_out/<tag>.log
+# in the order the driver's run creates them): bash scripts/scratch/dev_headline_matrix.sh > gpurun_out/<tag>.log
 cd "$GRAFT_REPO_ROOT" || exit 1
 for q in 1 2 4 8; do
   for ls in 0 1; do

@@ -1,6 +1,6 @@
 #!/bin/bash
 # One-line-per-setting timing of the headline unit under tuning knobs given as arguments, e.g.
-#   bash scripts/dev_knobs.sh "" "GPFIT_FORK_EARLY=1" "GPFIT_SIDE_MIN=2048"
+#   bash scripts/scratch/dev_knobs.sh "" "GPFIT_FORK_EARLY=1" "GPFIT_SIDE_MIN=2048"
 cd "$GRAFT_REPO_ROOT" || exit 1
 for kv in "$@"; do
   echo "[$kv]"

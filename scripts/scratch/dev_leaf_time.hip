@@ -1,5 +1,5 @@
 // Phase timing inside the register-resident leaf (dev tool):
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -Iinclude -Igaussian_processes_amd/csrc scripts/dev_leaf_time.hip -o /tmp/leaf_time && /tmp/leaf_time
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -Iinclude -Igaussian_processes_amd/csrc scripts/scratch/dev_leaf_time.hip -o /tmp/leaf_time && /tmp/leaf_time
 // -DNO_STAMPS: the production kernel (no in-kernel stamps: each s_memtime sits on the critical path), timing only
 #ifndef NO_STAMPS
 #define GPFIT_LEAF_STAMPS 1

@@ -1,4 +1,4 @@
-"""A/B of the factorisation schedules: python scripts/dev_lockstep.py [N] [d] [reps]
+"""A/B of the factorisation schedules: python scripts/scratch/dev_lockstep.py [N] [d] [reps]
 Prints ms/fit, phases and the hex of every output scalar (run under GPFIT_LOCKSTEP=0/1, GPFIT_NO_BATCH=1 and diff)."""
 import os, sys, time
 import numpy as np, torch

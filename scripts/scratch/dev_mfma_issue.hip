@@ -1,5 +1,5 @@
 // How fast ONE wave can issue fp64 MFMAs on gfx950 (dev tool; calibrates the leaf's cycle budget):
-//   hipcc --offload-arch=gfx950 -O3 scripts/dev_mfma_issue.hip -o gpurun_tmp/mfma_issue && gpurun_tmp/mfma_issue
+//   hipcc --offload-arch=gfx950 -O3 scripts/scratch/dev_mfma_issue.hip -o gpurun_tmp/mfma_issue && gpurun_tmp/mfma_issue
 // chains = 1: every MFMA depends on the one before (same accumulator); chains = 3 / 9: round robin over independent accumulators.
 #include <hip/hip_runtime.h>
 #include <cstdio>

@@ -1,4 +1,4 @@
-"""Phase timing of the headline unit (no profiler): python scripts/dev_phases.py [N] [d] [reps]"""
+"""Phase timing of the headline unit (no profiler): python scripts/scratch/dev_phases.py [N] [d] [reps]"""
 import os, sys, time
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

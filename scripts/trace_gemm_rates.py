@@ -1,7 +1,7 @@
 """Pair the GEMM launch log of one evaluation (GPFIT_GEMM_LOG=k, stderr) with a rocprofv3 kernel trace of the same
 single-stream run: per launch shape, duration and executed TFLOP/s; totals by size class.
 
-    GPFIT_GEMM_LOG=3 GPFIT_SIDE_MIN=0 GPFIT_TS_SIDE=0 rocprofv3 --kernel-trace ... -- python scripts/dev_lockstep.py 2> log
+    GPFIT_GEMM_LOG=3 GPFIT_SIDE_MIN=0 GPFIT_TS_SIDE=0 rocprofv3 --kernel-trace ... -- python scripts/scratch/dev_lockstep.py 2> log
     python scripts/trace_gemm_rates.py <kernel_trace.csv> <log> <k>"""
 import collections, csv, re, sys
 trace, log, k = sys.argv[1], sys.argv[2], int(sys.argv[3])

@@ -202,6 +202,19 @@ def g3():
     save("g3_closure_sparse_N96_nt40.npz", **closure_case(96, 64, 1e-14, ntilde=40))
 
 
+def g3_config_size():
+    """The regime the reference actually runs (default EIGVAL_TOL, where every fit from N = 1024 up truncates) at the
+    size of BASELINE configs[1]: N = 4096, d = 256, truncated (n_tilde = n_t) and sparse (n_tilde = 2048).  Inputs
+    regenerate from the seed; only the reference's outputs are stored.  The closure value does not depend on which
+    orthonormal basis of the kept eigenspace B is (m_b = B^T m, V_b = B^T V B are formed from the same m, V by both
+    sides), so the GPU side may build its basis by subspace iteration and still has to land on these numbers."""
+    for name, ntilde in (("g3_closure_trunc_N4096_d256.npz", None), ("g3_closure_sparse_N4096_nt2048_d256.npz", 2048)):
+        c = closure_case(4096, 256, 1e-4, ntilde=ntilde, store_inputs=False)
+        print(name, "kept", c["n_kept"], "of", c["ntilde"], "loss", c["loss"])
+        assert c["n_kept"] < c["ntilde"]
+        save(name, **c)
+
+
 # ------------------------------------------------------------------ G4 Estep
 def g4(N=64, store_K=True):
     """Estep (utils.py:1402-1439) in the reference's eigenbasis, mapped back to the original basis.
@@ -258,15 +271,15 @@ def g5():
 
 
 # ------------------------------------------------------------------ G6 varGP end to end
-def g6(tol, name, dup=0, ntilde=None):
+def g6(tol, name, dup=0, ntilde=None, N=128, nEstep=2, nMstep=3, nFparamstep=3, lean=False):
     ref.EIGVAL_TOL = tol
-    N, d = 128, 64
+    d = 64
     ntilde = ntilde or N
     X = torch.from_numpy(near_duplicate(syn.stimuli(N, d, seed=0), dup))
     r_np, _ = syn.cell_inputs(N)
     r = torch.from_numpy(r_np)
     th = syn.theta0()
-    fit_parameters = {"ntilde": ntilde, "maxiter": 4, "nEstep": 2, "nMstep": 3, "nFparamstep": 3,
+    fit_parameters = {"ntilde": ntilde, "maxiter": 4, "nEstep": nEstep, "nMstep": nMstep, "nFparamstep": nFparamstep,
                       "kernfun": "acosker", "cellid": 0, "n_px_side": 8, "display_hyper": False}
     args = {"fit_parameters": fit_parameters, "xtilde": X[:ntilde].clone(),
             "hyperparams_tuple": (tth(th), lower, upper),
@@ -284,15 +297,28 @@ def g6(tol, name, dup=0, ntilde=None):
         # the at_iteration branch (utils.py:358-386): kernel / eigenbasis rebuilt from the tracked theta
         _, R_pred_it2, _, _ = ref.test(Xs, Rt, X_train=X, at_iteration=2, **fit)
     print(name, "kept", fit["B"].shape[1], "of", ntilde)
-    save(name, tol=tol, N=N, d=d, dup=dup, ntilde=ntilde, X=X.numpy(), r=r_np, theta0=thvec(th),
-         maxiter=4, nEstep=2, nMstep=3, nFparamstep=3,
+    # kept eigen-dimension of every tracked iteration (the rank decision the reference took there, utils.py:1683/1809)
+    n_kept_track = np.array([v.shape[0] for v in vt["variation_par_track"]["V_b"]])
+    if lean:
+        # a fixture of a few KiB: X and r regenerate from the seed (syn.stimuli(N, d, seed=0), syn.cell_inputs(N)); the
+        # posterior is stored in the ORIGINAL basis (basis-independent) as its mean, the diagonal of its covariance
+        # and the covariance applied to a seeded probe vector
+        Bf = fit["B"]
+        V_orig = Bf @ fit["V_b"] @ Bf.T
+        probe = torch.from_numpy(np.random.default_rng(77).standard_normal(ntilde))
+        big = dict(m_orig=(Bf @ fit["m_b"]).numpy(), V_orig_diag=torch.diagonal(V_orig).numpy(),
+                   V_orig_probe=(V_orig @ probe).numpy(), probe_seed=77)
+    else:
+        big = dict(X=X.numpy(), r=r_np, m_b=fit["m_b"].numpy(), V_b=fit["V_b"].numpy(), B=fit["B"].numpy())
+    save(name, tol=tol, N=N, d=d, dup=dup, ntilde=ntilde, theta0=thvec(th), **big,
+         maxiter=4, nEstep=nEstep, nMstep=nMstep, nFparamstep=nFparamstep, n_kept_track=n_kept_track,
          logmarginal=vt["loss_track"]["logmarginal"].numpy(), loglikelihood=vt["loss_track"]["loglikelihood"].numpy(),
          KL=vt["loss_track"]["KL"].numpy(),
          theta_track=np.stack([vt["theta_track"][k].numpy() for k in KEYS]),
          logA_track=vt["f_par_track"]["logA"].numpy(), lambda0_track=vt["f_par_track"]["lambda0"].numpy(),
          theta_final=np.array([float(fit["hyperparams_tuple"][0][k]) for k in KEYS]),
          logA_final=float(fit["f_params"]["logA"]), lambda0_final=float(fit["f_params"]["lambda0"]),
-         m_b=fit["m_b"].numpy(), V_b=fit["V_b"].numpy(), B=fit["B"].numpy(), n_kept=fit["B"].shape[1],
+         n_kept=fit["B"].shape[1],
          Xstar=Xs.numpy(), R_pred=R_pred.numpy(), R_pred_it2=R_pred_it2.numpy())
     ref.EIGVAL_TOL = 1e-4
 
@@ -305,8 +331,8 @@ class FaultInjected(RuntimeError):
 def inject_localker_fault(mod, nth):
     """Replace ``mod.localker`` by a wrapper that raises on its nth call with grad=False (the kernel
     rebuild at the top of an EM iteration, utils.py:1803; the M-step closure asks for grad=True).
-    Returns the restore function.  Shared with tests/test_gpu_dropin.py (fault injection on the
-    drop-in module through the same module-level name)."""
+    Returns the restore function.  (The GPU test injects its fault into the drop-in module through the same
+    module-level name with its own few lines: this file stays in the build container.)"""
     orig = mod.localker
     count = [0]
 
@@ -512,6 +538,13 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "g8":
         g8()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "g3big":
+        g3_config_size()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "g6c0":
+        # BASELINE configs[0] (one_cell_fit.ipynb:384,390 at N = 512, d = 64) at the reference's default tolerance
+        g6(1e-4, "g6_vargp_config0_N512.npz", N=512, nEstep=5, nMstep=5, nFparamstep=3, lean=True)
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "g6s":
         g6(1e-4, "g6_vargp_sparse_N128_nt64.npz", ntilde=64)
         sys.exit(0)
@@ -528,3 +561,5 @@ if __name__ == "__main__":
     g8()
     g9()
     g10()
+    g3_config_size()
+    g6(1e-4, "g6_vargp_config0_N512.npz", N=512, nEstep=5, nMstep=5, nFparamstep=3, lean=True)

@@ -184,3 +184,41 @@ def test_grouped_driver_pipelined_keeps_one_group_in_flight():
     one = multi.evaluate_units_grouped(units, lambda us: finish(begin(us, 0), 0), torch.device("cpu"), group=4, begin_fn=begin,
                                        finish_fn=finish, sets=1)
     assert torch.equal(one, plain) and [e[0] for e in log] == ["begin", "finish"] * 3
+
+
+def test_grouped_driver_without_group_fn_and_with_a_failing_group():
+    """evaluate_units_grouped with only begin_fn / finish_fn: one set of engines runs begin + finish back to back
+    (no group_fn needed); two sets pipeline one deep -- and when a group fails, the group already enqueued is still
+    collected before the error propagates, so its contexts are not left pending."""
+    dev = torch.device("cpu")
+    log = []
+
+    def begin(us, slot):
+        log.append(("begin", tuple(us), slot))
+        if 5 in us:
+            raise RuntimeError("boom")
+        return list(us)
+
+    def finish(handle, slot):
+        log.append(("finish", tuple(handle), slot))
+        return [[float(u)] * multi.RESULT_WIDTH for u in handle]
+
+    t1 = multi.evaluate_units_grouped([0, 1, 2], None, dev, 2, begin_fn=begin, finish_fn=finish, sets=1)
+    assert t1[:, 0].tolist() == [0.0, 1.0, 2.0]
+    assert log == [("begin", (0, 1), 0), ("finish", (0, 1), 0), ("begin", (2,), 0), ("finish", (2,), 0)]
+    del log[:]
+    t2 = multi.evaluate_units_grouped([0, 1, 2, 3], None, dev, 2, begin_fn=begin, finish_fn=finish, sets=2)
+    assert t2[:, 0].tolist() == [0.0, 1.0, 2.0, 3.0]
+    assert log == [("begin", (0, 1), 0), ("begin", (2, 3), 1), ("finish", (0, 1), 0), ("finish", (2, 3), 1)]
+    del log[:]
+    try:
+        multi.evaluate_units_grouped([0, 1, 4, 5], None, dev, 2, begin_fn=begin, finish_fn=finish, sets=2)
+        raise AssertionError("the failing group must propagate")
+    except RuntimeError as err:
+        assert str(err) == "boom"
+    assert log == [("begin", (0, 1), 0), ("begin", (4, 5), 1), ("finish", (0, 1), 0)]      # the pending group was drained
+    try:
+        multi.evaluate_units_grouped([0], None, dev, 1)
+        raise AssertionError("no evaluator at all must be refused")
+    except ValueError:
+        pass

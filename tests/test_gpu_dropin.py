@@ -1023,3 +1023,7 @@ def test_closed_loop_step_matches_reference(gp):
     slow = gp.extend_inducing_set(bare, images[rest[pick]])
     assert slow["init_kernel"]["basis_route"] == "identity" and torch.equal(slow["init_kernel"]["K_tilde"], ik["K_tilde"])
     assert relerr(slow["init_kernel"]["K_tilde_inv_b"].cpu().numpy(), ik["K_tilde_inv_b"].cpu().numpy()) < 1e-9
+    # the prepared init_kernel is the kernel of ONE training set (the grown inducing set): any other is refused
+    with pytest.raises(ValueError, match="extend_inducing_set"):
+        gp.varGP(images[: n0 + 5], spikes[: n0 + 5], fit_parameters=again, xtilde=grown["xtilde"],
+                 hyperparams_tuple=first["hyperparams_tuple"], f_params=first["f_params"], m=grown["m"], V=grown["V"], init_kernel=ik)

@@ -78,7 +78,7 @@ def test_theta_grid_meets_the_north_star_tolerance():
     Yardstick: the fp64 instance of this library on the same lattice (the reference has no reduced-precision mode,
     utils.py:31-33; the fp64 instance is oracle-checked at this size in tests/test_gpu_parity.py) -- a yardstick,
     not a second pin.  The all-fp32 instance misses the bar on part of the lattice (2.8e-5 at corner 448; measured
-    with scripts/dev_fp32_err.py: rounding K~, V, m to fp32 moves the loss by 1e-8 -- it is the fp32 ARITHMETIC of
+    with scripts/scratch/dev_fp32_err.py: rounding K~, V, m to fp32 moves the loss by 1e-8 -- it is the fp32 ARITHMETIC of
     the factorisations, log|K~| off by +0.5 .. +1.7, that does it), so the configuration runs in the mixed mode:
     kernel build, both Cholesky factorisations, both log-determinants, the likelihood and m^T K~^-1 m in fp64; the
     N^3-heavy products T, Q, W and the pull-back in fp32 -- including T's norm, i.e. the trace term tr(K~^-1 V) of

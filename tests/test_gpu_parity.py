@@ -346,15 +346,17 @@ def test_pipelined_units_match_sequential(dev):
         e.close()
 
 
-def test_config3_64_cells_N4096_four_in_flight(dev):
-    """BASELINE configs[3] at its real size: 64 independent cells x N = 4096, d = 128 (rectangular 16 x 8 grid),
-    X shared, every cell its own receptive-field centre (theta), r, m and V, four cells in flight on four
-    contexts / streams -- what `bench.py --config cells64` times.  All 64 results are bit-identical to the
-    one-at-a-time driver; cells 0, 37 and 63 are checked against the oracle (1e-9 / 1e-6)."""
+def test_config3_64_cells_N4096_in_groups_of_16(dev):
+    """BASELINE configs[3] at its real size, through the route `bench.py --config cells64` times: 64 independent cells
+    x N = 4096, d = 128 (rectangular 16 x 8 grid), X shared, every cell its own receptive-field centre (theta), r, m
+    and V, evaluated 16 at a time by `gpfit_fit_eval_batch` (lock-step factorisations, pointer-batched products,
+    `post_join_list`) on two sets of 16 contexts, the next group enqueued before the previous one is collected
+    (`multi.evaluate_units_grouped(..., sets=2)`).  All 64 rows are bit-identical to the one-at-a-time driver on a
+    single context; cells 0, 37 and 63 are checked against the oracle (1e-9 / 1e-6)."""
     from gaussian_processes_amd import multi
-    from gaussian_processes_amd.engine import GPFitEngine
+    from gaussian_processes_amd.engine import GPFitEngine, fit_eval_group_begin, fit_eval_group_finish
     from gaussian_processes_amd import utils as gp
-    N, d, cells, depth = 4096, 128, 64, 4
+    N, d, cells, group, sets = 4096, 128, 64, 16, 2
     grid = syn.grid_for(d)
     Xh = T(syn.stimuli(N, d))
     Xd = Xh.to(dev)
@@ -366,32 +368,33 @@ def test_config3_64_cells_N4096_four_in_flight(dev):
         assert bool(mask.all())
         V = 0.5 * gp.acosker(th0, Xd, Xd, C=C)
         inputs[c] = (T(rc).to(dev), T(mc).to(dev), V, syn.theta_eval(c))
-    engs = [GPFitEngine(N, d) for _ in range(depth)]
-    streams = [torch.cuda.Stream() for _ in engs]
+    engs = [GPFitEngine(N, d) for _ in range(group * sets)]
     torch.cuda.synchronize()
+
+    def rows_of(res):
+        return [[o["loss"]] + [o["grad"][k] for k in KEYS] for o in res]
 
     def eval_cell(c):
         r, m, V, th = inputs[c]
-        o = engs[0].fit_eval(th, LOWER, UPPER, grid, Xd, r, m, V, LOGA, LAM0, want_vectors=False)
-        return [o["loss"]] + [o["grad"][k] for k in KEYS]
+        return rows_of([engs[0].fit_eval(th, LOWER, UPPER, grid, Xd, r, m, V, LOGA, LAM0, want_vectors=False)])[0]
 
-    def submit(c, slot):
-        r, m, V, th = inputs[c]
-        with torch.cuda.stream(streams[slot]):
-            return engs[slot].fit_eval_async(th, LOWER, UPPER, grid, Xd, r, m, V, LOGA, LAM0, want_vectors=False)
+    def begin(cs, slot):
+        sel = [inputs[c] for c in cs]
+        return fit_eval_group_begin(engs[slot * group:(slot + 1) * group], [t[3] for t in sel], LOWER, UPPER, grid, Xd,
+                                    [t[0] for t in sel], [t[1] for t in sel], [t[2] for t in sel], LOGA, LAM0)
 
-    def collect(t, slot):
-        o = engs[slot].fit_eval_finish(t)
-        return [o["loss"]] + [o["grad"][k] for k in KEYS]
+    def finish(handle, slot):
+        return rows_of(fit_eval_group_finish(handle))
 
-    pipe = multi.run_sharded(cells, None, dev, submit_fn=submit, collect_fn=collect, depth=depth)
+    grouped = multi.run_sharded(cells, None, dev, group_fn=lambda cs: finish(begin(cs, 0), 0), group=group, begin_fn=begin,
+                                finish_fn=finish, sets=sets)
     seq = multi.run_sharded(cells, eval_cell, dev)
     for e in engs:
         e.close()
-    assert pipe.shape == (cells, 7) and torch.isfinite(pipe).all()
-    assert torch.equal(pipe, seq)
-    assert len({float(v) for v in pipe[:, 0]}) == cells            # 64 different cells, 64 different losses
-    table = pipe.cpu().numpy()
+    assert grouped.shape == (cells, 7) and torch.isfinite(grouped).all()
+    assert torch.equal(grouped, seq)
+    assert len({float(v) for v in grouped[:, 0]}) == cells            # 64 different cells, 64 different losses
+    table = grouped.cpu().numpy()
     for c in (0, 37, 63):
         r, m, V, th = inputs[c]
         loss, grad = orc.mstep_closure_cholesky(th, LOWER, UPPER, grid, Xh, r.cpu(), m.cpu(), V.cpu(), LOGA, LAM0)

@@ -4,7 +4,7 @@ unexamined near the reference's keep-all margin'.  The reference keeps all eigen
 cond(K~) < 1e4 (EIGVAL_TOL = 1e-4, utils.py:1683) and its fixtures' full-rank family runs at tol 1e-14,
 so the range examined is cond = 1e2 .. 1e14.
 
-Measured on MI355X (scripts/dev_stability.py, N = 1024): |L L^T - M| / |M| = 1e-15 .. 2e-15 at every
+Measured on MI355X (scripts/scratch/dev_stability.py, N = 1024): |L L^T - M| / |M| = 1e-15 .. 2e-15 at every
 condition number (LAPACK's potrf on the same matrices: 0.4e-15 .. 1.2e-15), |L^-1 L - I| follows
 eps * sqrt(cond) (1e-15 at 1e2, 1.5e-9 at 1e14), log|M| errors equal LAPACK's (both limited by
 cond * eps).  Asserted with a factor of ~10 of slack."""

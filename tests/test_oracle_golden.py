@@ -81,11 +81,12 @@ def _closure_inputs(g):
         X, r, B, m_b, V_b = T(g["X"]), T(g["r"]), T(g["B"]), T(g["m_b"]), T(g["V_b"])
     else:  # inputs regenerated from the seed (fixture stores outputs only)
         X = T(syn.stimuli(N, d, seed=int(g["seed"])))
+        nt_ = int(g["ntilde"])
         r_np, m_np = syn.cell_inputs(N)
-        r, m = T(r_np), T(m_np)
+        r, m = T(r_np), T(m_np[:nt_].copy())
         th0 = thd(g["theta0"])
         C0, mask0 = orc.spatial_metric(th0, LOWER, UPPER, int(g["n_px"]))
-        Kt0 = orc.arccos_gram(th0, X[:, mask0], X[:, mask0], C0)
+        Kt0 = orc.arccos_gram(th0, X[:nt_, mask0], X[:nt_, mask0], C0)
         V = 0.5 * Kt0
         ev, evec, keep = orc.eigen_basis(Kt0, float(g["tol"]))
         assert int(keep.sum()) == int(g["n_kept"])
@@ -112,6 +113,26 @@ def test_g3_closure_reference_formulation(name):
     assert relerr(gv, g["grad"]) < 1e-8
     assert relerr(parts["lam_m"], g["lam_m"]) < 1e-11
     assert relerr(parts["lam_var"], g["lam_var"]) < 1e-10
+
+
+@pytest.mark.parametrize("name", ["g3_closure_trunc_N4096_d256.npz", "g3_closure_sparse_N4096_nt2048_d256.npz"])
+def test_g3_closure_reference_formulation_at_config_size(name):
+    """The oracle in the regime the reference actually runs (default EIGVAL_TOL: 515 of 4096 / 534 of 2048 kept) at
+    N = 4096, d = 256 -- the size of BASELINE configs[1] and of `bench.py --config trunc / sparse`'s CPU leg."""
+    g = load_golden(name)
+    X, r, B, m_b, V_b = _closure_inputs(g)
+    nt_ = int(g["ntilde"])
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        loss, grad, parts = orc.mstep_closure_reference(
+            thd(g["theta"]), LOWER, UPPER, int(g["n_px"]), X, X[:nt_], r, B, m_b, V_b,
+            float(g["logA"]), float(g["lambda0"]), tol=float(g["tol"]), want_parts=True)
+    assert abs(loss - float(g["loss"])) <= 1e-10 * abs(float(g["loss"]))
+    assert abs(parts["KL"] - float(g["KL"])) <= 1e-10 * abs(float(g["KL"]))
+    assert abs(parts["loglik"] - float(g["loglik"])) <= 1e-10 * abs(float(g["loglik"]))
+    assert relerr(np.array([grad[k] for k in KEYS]), g["grad"]) < 1e-7
+    assert relerr(parts["lam_m"], g["lam_m"]) < 1e-9
+    assert relerr(parts["lam_var"], g["lam_var"]) < 1e-9
 
 
 @pytest.mark.parametrize("name", ["g3_closure_full_N64.npz", "g3_closure_full_N256.npz",
