@@ -49,35 +49,114 @@ def _cholqr(Y, matmul, cholesky, rounds):
     return Y
 
 
+def _chebyshev_shifts(a, m):
+    """The m roots of the Chebyshev polynomial of the interval [0, a], largest and smallest alternating.  One sweep
+    with each of them as its shift applies (K - s_1) ... (K - s_m), the degree-m polynomial that is smallest on
+    [0, a] for its growth outside: a kept direction (lambda >= tau > a) gains 1 / T_m((2 tau - a) / a) on everything
+    left outside the block, against (a / tau)^m for m unshifted sweeps.  Every factor is a contraction on its own
+    (|lambda - s| <= a < tau - s for lambda in [0, a], as long as a < tau / 2 ... 0.6 tau), so the order only matters
+    for how evenly the gain arrives."""
+    import math
+    roots = [0.5 * a * (1.0 + math.cos((2 * j - 1) * math.pi / (2 * m))) for j in range(1, m + 1)]
+    order, lo, hi = [], 0, m - 1
+    while lo <= hi:
+        order.append(roots[lo]); lo += 1
+        if lo <= hi:
+            order.append(roots[hi]); hi -= 1
+    return order
+
+
+# what the kept directions must gain on everything the random start block left outside the block before the first
+# Rayleigh-Ritz check (certificate 1e-7 with a factor three in hand; calibrated on k = 2 n and k = 1.5 n blocks of the
+# fit's kernel matrices, profiles/r04_eigtop.log)
+_GAIN_NEEDED = 7e7
+
+
+def _filter_gain(applied, a, tau):
+    """|p(tau)| / max_{[0, a]} |p| of the polynomial the sweeps so far have applied, p(x) = prod (x - s_j) (s_j = 0:
+    an unshifted sweep), on a grid of [0, a]."""
+    if not applied:
+        return 1.0
+    lam = torch.linspace(0.0, float(a), 257, dtype=torch.float64)
+    p = torch.ones_like(lam)
+    num = 1.0
+    for sg in applied:
+        p = p * (lam - sg).abs() / (tau - sg)       # ratios keep the product in range
+    return 1.0 / max(float(p.max()), 1e-300)
+
+
 def top_eigenpairs(K, tol, matmul, cholesky, k0=None, first_sweeps=None, max_sweeps=60, angle_tol=1e-7, seed=20240229,
-                   log=None):
+                   log=None, accelerate=True):
     """Eigenpairs of the symmetric positive definite ``K`` with ``lambda > max(lambda_max * tol, tol)``.
 
     Returns ``(eigenvalues ascending [n], eigenvectors [N, n], info)`` or ``None`` when the caller should fall
     back to a full eigendecomposition.  ``matmul`` / ``cholesky`` are the library's GEMM and Cholesky wrappers
-    (``utils.matmul``, ``utils.cholesky``)."""
+    (``utils.matmul``, ``utils.cholesky``).
+
+    ``accelerate`` (round 4): every sweep after the first is shifted, ``Q <- orth((K - s I) Q)``, the shifts running
+    through the roots of the Chebyshev polynomial of ``[0, a]``, ``a`` = the smallest Rayleigh quotient of the block
+    (an upper bound of everything outside the block; available from the sweep's own product).  The spectrum of these
+    kernel matrices has no gap at the threshold -- with a block of twice the kept count the first dropped-out
+    eigenvalue is still tau / 4 -- so plain sweeps contract by 0.25 each (16 of them for the 1e-7 certificate);
+    the shifted ones by 0.08 (9).  The orthonormalisation after EVERY sweep stays: one factor spreads the
+    block over lambda_max / tau = 1e4, two would exceed what a Gram matrix in fp64 resolves."""
     import math
     N = K.shape[0]
     dev, dt = K.device, K.dtype
     gen = torch.Generator(device=dev)
     gen.manual_seed(seed)
     k = min(k0 or (1024 if N >= 4096 else 512), N)
+    # How many sweeps before the first Rayleigh-Ritz check?  That k x k eigenproblem is the expensive step at the sizes
+    # this solver serves (24 ms at k = 1024 against 3.3 ms per sweep at N = 8192), so the first check should pass.
+    # Plain sweeps: a fixed 16 (8 below N = 4096), the measured need of the fit's kernel matrices.  Accelerated: planned
+    # after the first (unshifted) sweep from the block's own Rayleigh quotients -- the Chebyshev gain per sweep is
+    # g = t + sqrt(t^2 - 1), t = (2 tau - a) / a, and the polynomial applied must reach _GAIN_NEEDED at tau against its
+    # maximum over [0, a]; ``first_sweeps`` overrides either.
+    dynamic = accelerate and first_sweeps is None
     if first_sweeps is None:
-        # the k x k Rayleigh-Ritz eigenproblem is the expensive step at the sizes this solver serves (23 ms at
-        # k = 1024 against 4 ms per sweep at N = 8192): sweep long enough for the FIRST check to pass on kernel
-        # matrices of the fit (16 sweeps: one check, 81 ms; 8 sweeps: two checks, 105 ms -- profiles/r03_eigtop.log)
-        first_sweeps = 16 if N >= 4096 else 8
+        first_sweeps = (9 if accelerate else 16) if N >= 4096 else 8
     Q = torch.randn((N, k), generator=gen, device=dev, dtype=dt)
     done, sweeps = 0, first_sweeps
     info = {"products": 0, "grown": 0, "rr": 0}
+    a_block = None          # upper bound of the spectrum outside the block, from the last Rayleigh-Ritz step
     while True:
         if k > N // 3:
             return None                      # not a truncation problem any more: a full eigh is the right tool
-        for i in range(sweeps):
-            Q = _cholqr(matmul(K, Q), matmul, cholesky, 2 if i == sweeps - 1 else 1)
+        shifts, applied = [], []
+        i = 0
+        while i < sweeps:
+            Y = matmul(K, Q)
             info["products"] += 1
+            if accelerate and (i > 0 or a_block is not None):
+                if not shifts:
+                    if a_block is None:
+                        # Rayleigh quotients of the columns after the one unshifted sweep: max <= lambda_max (tau_est <=
+                        # tau), min >= the smallest Ritz value of the block >= lambda_{k+1}, the top of the spectrum the
+                        # block leaves outside.  Only an UNSHIFTED sweep gives that bound: a shifted sweep damps [0, a]
+                        # inside the block too, the lowest quotients then drop below lambda_{k+1} (measured: 0.18 tau
+                        # against 0.25 tau) and an interval planned from them would leave (0.18, 0.25] tau undamped.
+                        rq = (Q * Y).sum(0)
+                        tau_est = max(float(rq.max()) * tol, tol)
+                        a = min(float(rq.min()), 0.6 * tau_est)
+                        if dynamic and a > 0:
+                            t = (2.0 * tau_est - a) / a
+                            g = t + math.sqrt(max(t * t - 1.0, 0.0))
+                            still = _GAIN_NEEDED * max(1.0, 1e-7 / angle_tol) / _filter_gain(applied, a, tau_est)
+                            m = math.ceil(math.log(2.0 * max(still, 1.0)) / math.log(g))       # T_m(t) ~ g^m / 2
+                            sweeps = i + int(min(max(m, 2), 24))
+                    else:
+                        a = a_block
+                    shifts = _chebyshev_shifts(a, sweeps - i) if a > 0 else [0.0] * (sweeps - i)
+                sigma = shifts.pop(0)
+                if sigma != 0.0:
+                    Y.sub_(Q, alpha=sigma)
+                applied.append(sigma)
+            else:
+                applied.append(0.0)
+            Q = _cholqr(Y, matmul, cholesky, 2 if i == sweeps - 1 else 1)
             if Q is None:
                 return None
+            i += 1
         done += sweeps
         Y = matmul(K, Q)
         info["products"] += 1
@@ -89,8 +168,8 @@ def top_eigenpairs(K, tol, matmul, cholesky, k0=None, first_sweeps=None, max_swe
         n = int((theta > tau).sum())
         # the block must reach well below the threshold, otherwise kept directions converge slowly (and eigenvalues
         # above the threshold may still be missing from it)
-        if float(theta[0]) > 0.5 * tau:
-            grow = min(k, N - k)
+        if float(theta[0]) > (0.6 if accelerate else 0.5) * tau:
+            grow = min(k if not accelerate else max(256, (k // 4 + 127) // 128 * 128), N - k)
             Q = torch.cat([Q, torch.randn((N, grow), generator=gen, device=dev, dtype=dt)], dim=1)
             Q = _cholqr(Q, matmul, cholesky, 2)
             if Q is None:
@@ -98,6 +177,7 @@ def top_eigenpairs(K, tol, matmul, cholesky, k0=None, first_sweeps=None, max_swe
             k += grow
             info["grown"] += 1
             sweeps = first_sweeps
+            a_block = None
             continue
         lo = max(0, k - n - 8)                                  # the kept pairs and a few below the threshold
         Zs = Z[:, lo:].contiguous()
@@ -119,14 +199,19 @@ def top_eigenpairs(K, tol, matmul, cholesky, k0=None, first_sweeps=None, max_swe
             sign[sign == 0] = 1.0
             below = theta[lo:][~kept]
             gap_thr = float(vals[0] - below[-1]) if (n > 0 and below.numel() > 0) else float("inf")
-            info.update({"k": k, "sweeps": done, "angle": angle, "n": n,
+            info.update({"k": k, "sweeps": done, "angle": angle, "n": n, "theta_min_over_tau": float(theta[0]) / tau,
                          "angle_kept_vs_dropped": float(res[kept].max()) / gap_thr if (n > 0 and gap_thr > 0) else 0.0})
             return vals.contiguous(), (vecs * sign).contiguous(), info
         if done >= max_sweeps:
             return None
-        # every sweep contracts the kept directions by at least theta_min(block) / tau: sweeps still needed for the
-        # angle bound to pass, with two in reserve (the Ritz value overestimates lambda_{k+1} a little)
-        rho = min(0.9, max(float(theta[0]) / tau, 1e-3))
+        # sweeps still needed for the angle bound to pass, with two in reserve (the Ritz value overestimates
+        # lambda_{k+1} a little): plain sweeps contract the kept directions by theta_min(block) / tau each, the
+        # Chebyshev-shifted ones by 1 / (t + sqrt(t^2 - 1)), t = (2 tau - a) / a
+        a_block = float(theta[0])
+        rho = min(0.9, max(a_block / tau, 1e-3))
+        if accelerate:
+            t = (2.0 * tau - a_block) / a_block
+            rho = min(0.9, 1.0 / (t + math.sqrt(max(t * t - 1.0, 0.0))))
         need = math.log(max(angle, 1e-300) / (0.3 * angle_tol)) / -math.log(rho) if angle > 0 else 1
         sweeps = int(min(max(2, math.ceil(need) + 2), max_sweeps - done, 24))
         Q = matmul(Q, Z)                                         # continue from the Ritz basis (same span)

@@ -735,7 +735,7 @@ def _stabilised_basis(K_tilde, route=None):
 
     def truncated_basis():
         # truncated regime: only the kept eigenpairs, by block subspace iteration on the library's GEMM and
-        # Cholesky (eigtop.py; 105 ms against 670 ms for the full eigh at N = 8192, same eigenvalues to
+        # Cholesky (eigtop.py; 56 ms against 670 ms for the full eigh at N = 8192, same eigenvalues to
         # 1e-14 and the same invariant subspace to 1e-13).  None: inconclusive -> the reference's own eigh.
         top = eigtop.top_eigenpairs(K_tilde, EIGVAL_TOL, matmul, cholesky) if n >= _EIGTOP_MIN_N else None
         if top is None:
