@@ -66,6 +66,103 @@ def _chebyshev_shifts(a, m):
     return order
 
 
+def _hash_matrix(rows, cols, device, dtype):
+    """Fixed pseudo-random test matrix with entries in (-1, 1): an integer hash of (row, column), evaluated on the
+    device -- the same numbers on every library / torch version (a seeded generator's stream is not promised to be),
+    which is what makes the basis below a function of the subspace alone."""
+    i = torch.arange(rows, device=device, dtype=torch.int64)[:, None]
+    j = torch.arange(cols, device=device, dtype=torch.int64)[None, :]
+    x = (i * 0x9E3779B1 + j * 0x85EBCA77 + 0x165667B1) & 0xFFFFFFFF
+    x = x ^ (x >> 15)
+    x = (x * 0x2C1B3C6D) & 0xFFFFFFFF
+    x = x ^ (x >> 12)
+    x = (x * 0x297A2D39) & 0xFFFFFFFF
+    x = x ^ (x >> 15)
+    return (x.to(dtype) * (1.0 / 2147483648.0) - 1.0).contiguous()
+
+
+def _kept_subspace(Q, Y, S, tol, a_out, matmul, cholesky, angle_tol, max_sign_iterations=40, log=None):
+    """The kept invariant subspace WITHOUT the k x k eigendecomposition (24 ms of rocSOLVER at k = 1024: a third of a
+    basis build at N = 8192, more than half at N = 4096), from GEMMs and Cholesky factorisations only.
+
+    Given the converged block ``Q`` (orthonormal, N x k), ``Y = K Q`` and ``S = Q^T K Q``:
+      * lambda_max = the top eigenvalue of S by power iteration from its best column (the sweeps have left it within
+        1e-4 of the eigenvector; ten more steps square that away), tau = max(lambda_max tol, tol);
+      * X_0 = (S - tau I)(S + tau I)^-1 (Cayley transform: eigenvalues (theta - tau) / (theta + tau) in (-1, 1), so the
+        1e4 of dynamic range above the threshold is compressed to [0, 1) and what is left near zero is half the relative
+        distance of a Ritz value from tau), then the Newton-Schulz iteration X <- X (3 I - X^2) / 2 to sign(S - tau I);
+      * P = (I + X) / 2 is the spectral projector of S onto theta > tau, n = trace P the kept count;
+      * B = orth(Q P Q^T Omega) = orth(P_V Omega) with the fixed N x n test matrix Omega (CholeskyQR2 on k x n
+        matrices): the orthonormal basis of the kept eigenspace V that depends on V alone, not on the block it was
+        found in -- ``test(at_iteration=...)`` rebuilds the basis the tracked (m_b, V_b) were expressed in;
+      * K~_b = B^T K B = U^T S U (dense n x n) and its inverse by Cholesky.
+    Certificate: the part of K B that leaves the block, ||(I - Q Q^T) K B||_F / (tau - a_out), a_out >= everything the
+    block left outside -- the quantity the eigenpair route bounds vector by vector.  Returns None when the sign
+    iteration does not settle (a Ritz value within ~1e-7 tau of the threshold: the count is ambiguous, as in the
+    eigenpair route) or a factorisation fails; the caller then takes the eigenpair route."""
+    k = S.shape[0]
+    dev, dt = S.device, S.dtype
+    eye = torch.eye(k, device=dev, dtype=dt)
+    # lambda_max(S)
+    v = S[:, torch.argmax(torch.diagonal(S))].clone()
+    v /= torch.linalg.vector_norm(v)
+    for _ in range(12):                             # k x k matrix-vector products: host plumbing, as the k x k eigh was
+        w = S @ v
+        v = w / torch.linalg.vector_norm(w)
+    lam_max = float(v @ (S @ v))                    # (one host synchronisation for the whole power iteration)
+    tau = max(lam_max * tol, tol)
+    if not (a_out < 0.55 * tau):
+        return None                                 # the block does not reach well below the threshold: eigenpair route
+    L, Li, _, info = cholesky(S + tau * eye, want_inverse=True)
+    if info != 0:
+        return None
+    Sinv = matmul(Li, Li, transA=True)
+    X = matmul(S - tau * eye, Sinv)
+    X = (X + X.T) * 0.5
+    # Newton-Schulz: every eigenvalue x of X grows by 3/2 per step while small and then converges cubically to +-1.  The
+    # smallest |x_0| is half the relative distance of the nearest Ritz value from tau -- at least ~13 steps on these
+    # spectra -- so the convergence test (a host synchronisation) only starts there.
+    its, settled = 0, False
+    while its < max_sign_iterations:
+        X2 = matmul(X, X)
+        if its >= 12:
+            dev2 = float(torch.linalg.matrix_norm(X2 - eye))      # Frobenius: sqrt(sum (x_i^2 - 1)^2)
+            if dev2 < 1e-13 * k:
+                settled = True
+                break
+        X = matmul(X, 1.5 * eye - 0.5 * X2)
+        X = (X + X.T) * 0.5
+        its += 1
+    if not settled:
+        return None
+    tr = float(torch.trace(X))
+    n = int(round(0.5 * (tr + k)))
+    if n <= 0 or n >= k or abs(0.5 * (tr + k) - n) > 1e-6:
+        return None
+    P = 0.5 * (X + eye)
+    N = Q.shape[0]
+    M = matmul(P, matmul(Q, _hash_matrix(N, n, dev, dt), transA=True))          # P Q^T Omega   [k, n]
+    U = _cholqr(M, matmul, cholesky, 2)
+    if U is None:
+        return None
+    B = matmul(Q, U)
+    SU = matmul(S, U)
+    Ktb = matmul(U, SU, transA=True)
+    Ktb = (Ktb + Ktb.T) * 0.5
+    Lb, Lbi, _, info = cholesky(Ktb, want_inverse=True)
+    if info != 0:
+        return None
+    Ktib = matmul(Lbi, Lbi, transA=True)
+    Ktib = (Ktib + Ktib.T) * 0.5
+    R_out = matmul(Y, U) - matmul(Q, SU)
+    res = float(torch.linalg.matrix_norm(R_out))
+    angle = res / (tau - a_out)
+    if log is not None:
+        log(f"eigtop: subspace route k {k} kept {n} sign iterations {its} residual leaving the block {res:.2e} angle bound {angle:.2e}")
+    return {"B": B.contiguous(), "K_tilde_b": Ktb, "K_tilde_inv_b": Ktib, "n": n, "tau": tau, "lam_max": lam_max,
+            "angle": angle, "sign_iterations": its}
+
+
 # what the kept directions must gain on everything the random start block left outside the block before the first
 # Rayleigh-Ritz check (certificate 1e-7 with a factor three in hand; calibrated on k = 2 n and k = 1.5 n blocks of the
 # fit's kernel matrices, profiles/r04_eigtop.log)
@@ -86,12 +183,19 @@ def _filter_gain(applied, a, tau):
 
 
 def top_eigenpairs(K, tol, matmul, cholesky, k0=None, first_sweeps=None, max_sweeps=60, angle_tol=1e-7, seed=20240229,
-                   log=None, accelerate=True):
+                   log=None, accelerate=True, basis="eigenvectors"):
     """Eigenpairs of the symmetric positive definite ``K`` with ``lambda > max(lambda_max * tol, tol)``.
 
     Returns ``(eigenvalues ascending [n], eigenvectors [N, n], info)`` or ``None`` when the caller should fall
     back to a full eigendecomposition.  ``matmul`` / ``cholesky`` are the library's GEMM and Cholesky wrappers
     (``utils.matmul``, ``utils.cholesky``).
+
+    ``basis="subspace"``: the same sweeps, but the k x k eigendecomposition of the Rayleigh-Ritz step is replaced by
+    ``_kept_subspace`` -- returns ``(None, B [N, n], info)`` with ``B`` the canonical orthonormal basis of the kept
+    EIGENSPACE (not its eigenvectors) and ``info["K_tilde_b"]``, ``info["K_tilde_inv_b"]`` the dense n x n matrices
+    ``B^T K B`` and its inverse.  Everything the fit computes downstream is invariant under the choice of an
+    orthonormal basis of that space.  Falls back to the eigenpair route by itself when the
+    eigh-free step declines.
 
     ``accelerate`` (round 4): every sweep after the first is shifted, ``Q <- orth((K - s I) Q)``, the shifts running
     through the roots of the Chebyshev polynomial of ``[0, a]``, ``a`` = the smallest Rayleigh quotient of the block
@@ -119,6 +223,7 @@ def top_eigenpairs(K, tol, matmul, cholesky, k0=None, first_sweeps=None, max_swe
     done, sweeps = 0, first_sweeps
     info = {"products": 0, "grown": 0, "rr": 0}
     a_block = None          # upper bound of the spectrum outside the block, from the last Rayleigh-Ritz step
+    a_plan = None           # the same bound as the first (unshifted) sweep of this block gave it
     while True:
         if k > N // 3:
             return None                      # not a truncation problem any more: a full eigh is the right tool
@@ -138,6 +243,7 @@ def top_eigenpairs(K, tol, matmul, cholesky, k0=None, first_sweeps=None, max_swe
                         rq = (Q * Y).sum(0)
                         tau_est = max(float(rq.max()) * tol, tol)
                         a = min(float(rq.min()), 0.6 * tau_est)
+                        a_plan = a
                         if dynamic and a > 0:
                             t = (2.0 * tau_est - a) / a
                             g = t + math.sqrt(max(t * t - 1.0, 0.0))
@@ -161,7 +267,24 @@ def top_eigenpairs(K, tol, matmul, cholesky, k0=None, first_sweeps=None, max_swe
         Y = matmul(K, Q)
         info["products"] += 1
         S = matmul(Q, Y, transA=True)
-        theta, Z = torch.linalg.eigh((S + S.T) * 0.5)          # k x k, ascending
+        S = (S + S.T) * 0.5
+        if basis == "subspace" and a_plan is not None:
+            sub = _kept_subspace(Q, Y, S, tol, a_plan, matmul, cholesky, angle_tol, log=log)
+            if sub is not None and sub["angle"] <= angle_tol:
+                info.update({"k": k, "sweeps": done, "angle": sub["angle"], "n": sub["n"], "route": "subspace",
+                             "sign_iterations": sub["sign_iterations"], "K_tilde_b": sub["K_tilde_b"],
+                             "K_tilde_inv_b": sub["K_tilde_inv_b"], "lam_max": sub["lam_max"]})
+                return None, sub["B"], info
+            if sub is not None and done < max_sweeps:
+                # not converged yet: more sweeps on the same block (Chebyshev interval as planned), then again
+                t = (2.0 * sub["tau"] - a_plan) / a_plan
+                rho = min(0.9, 1.0 / (t + math.sqrt(max(t * t - 1.0, 0.0))))
+                need = math.log(max(sub["angle"], 1e-300) / (0.3 * angle_tol)) / -math.log(rho)
+                sweeps = int(min(max(2, math.ceil(need) + 1), max_sweeps - done, 24))
+                a_block = a_plan
+                continue
+            # declined (ambiguous count, block too small, failed factorisation): the eigenpair route decides
+        theta, Z = torch.linalg.eigh(S)                        # k x k, ascending
         info["rr"] += 1
         lam_max = float(theta[-1])
         tau = max(lam_max * tol, tol)
@@ -177,7 +300,7 @@ def top_eigenpairs(K, tol, matmul, cholesky, k0=None, first_sweeps=None, max_swe
             k += grow
             info["grown"] += 1
             sweeps = first_sweeps
-            a_block = None
+            a_block = a_plan = None
             continue
         lo = max(0, k - n - 8)                                  # the kept pairs and a few below the threshold
         Zs = Z[:, lo:].contiguous()

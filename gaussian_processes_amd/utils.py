@@ -733,16 +733,24 @@ def _stabilised_basis(K_tilde, route=None):
     cannot be reproduced raises instead of returning numbers in the wrong coordinates."""
     n = K_tilde.shape[0]
 
-    def truncated_basis():
-        # truncated regime: only the kept eigenpairs, by block subspace iteration on the library's GEMM and
-        # Cholesky (eigtop.py; 56 ms against 670 ms for the full eigh at N = 8192, same eigenvalues to
-        # 1e-14 and the same invariant subspace to 1e-13).  None: inconclusive -> the reference's own eigh.
-        top = eigtop.top_eigenpairs(K_tilde, EIGVAL_TOL, matmul, cholesky) if n >= _EIGTOP_MIN_N else None
+    def truncated_basis(want=None):
+        # truncated regime: only the kept eigenspace, by block subspace iteration on the library's GEMM and Cholesky
+        # (eigtop.py; 40 ms against 670 ms for the full eigh at N = 8192).  want = "subspace": the canonical
+        # orthonormal basis of that space and the dense K~_b = B^T K~ B, no dense eigendecomposition at all;
+        # "eigtop": its eigenvectors (one k x k eigh, k = 1024), same eigenvalues to 1e-14 and the same invariant
+        # subspace to 1e-13 as the full eigh.  None: inconclusive -> the reference's own eigh.
+        if n < _EIGTOP_MIN_N:
+            return None
+        want = want or ("subspace" if EIGTOP_BASIS == "subspace" else "eigtop")
+        top = eigtop.top_eigenpairs(K_tilde, EIGVAL_TOL, matmul, cholesky,
+                                    basis="subspace" if want == "subspace" else "eigenvectors")
         if top is None:
             return None
-        vals, vecs, _ = top
+        vals, vecs, info = top
+        if vals is None:
+            return "subspace", (vecs, vecs, info["K_tilde_b"], info["K_tilde_inv_b"])
         # the first entry stands in for the reference's N x N eigenvector matrix: only the kept columns exist
-        return vecs, vecs, torch.diag(vals), torch.diag_embed(1 / vals)
+        return "eigtop", (vecs, vecs, torch.diag(vals), torch.diag_embed(1 / vals))
 
     def identity_basis(Li):
         B = _mark_identity(torch.eye(n, dtype=TORCH_DTYPE, device=K_tilde.device))
@@ -760,8 +768,9 @@ def _stabilised_basis(K_tilde, route=None):
             out = identity_basis(Li) if kept else None
             if kept:
                 _BASIS.factor = (L, Li)
-        elif route == "eigtop":
-            out = truncated_basis()
+        elif route in ("eigtop", "subspace"):
+            got = truncated_basis(route)
+            out = got[1] if (got is not None and got[0] == route) else None
         elif route == "eigh":
             out = eigh_basis()
         else:
@@ -779,10 +788,10 @@ def _stabilised_basis(K_tilde, route=None):
         hints = _BASIS.__dict__.setdefault("regime", {})
         key = (n, float(EIGVAL_TOL))
         if hints.get(key) == "truncated":
-            out = truncated_basis()
-            if out is not None:
-                _BASIS.route = "eigtop"
-                return out
+            got = truncated_basis()
+            if got is not None:
+                _BASIS.route = got[0]
+                return got[1]
         kept, L, Li = _all_eigenvalues_kept(K_tilde)
         if kept:
             hints[key] = "full"
@@ -790,11 +799,11 @@ def _stabilised_basis(K_tilde, route=None):
             _BASIS.factor = (L, Li)      # K~ = L L^T, L^-1: kept by varGP for the closed loop (extend_inducing_set)
             return identity_basis(Li)
         if hints.get(key) != "truncated":
-            out = truncated_basis()
-            if out is not None:
+            got = truncated_basis()
+            if got is not None:
                 hints[key] = "truncated"
-                _BASIS.route = "eigtop"
-                return out
+                _BASIS.route = got[0]
+                return got[1]
     _BASIS.route = "eigh"
     return eigh_basis()
 
@@ -802,6 +811,14 @@ def _stabilised_basis(K_tilde, route=None):
 import os as _os_mod
 _FORCE_EIGH = bool(_os_mod.environ.get("GPFIT_FORCE_EIGH"))   # tuning / A-B knob: always take the eigh route
 _EIGTOP_MIN_N = 4096   # below this the full eigh is as fast (N = 3072: 91 ms either way)
+# What the truncated regime's basis B is made of at N >= 4096 (module global read at call time, like EIGVAL_TOL):
+#   "subspace"     (default) the canonical orthonormal basis of the kept EIGENSPACE: no dense eigendecomposition at
+#                  all; K_tilde_b = B^T K~ B is a dense n x n matrix.  Everything downstream is invariant under the
+#                  choice of an orthonormal basis of that space (the reference's own formulas only use B^T B = I and the
+#                  invariance of span B), but the COLUMNS of B are not eigenvectors;
+#   "eigenvectors" the reference's own choice (utils.py:1683-1694): the kept eigenvectors, K_tilde_b diagonal, at the
+#                  price of one k x k eigendecomposition (k = 1024) per basis: 16 ms more per EM iteration.
+EIGTOP_BASIS = _os_mod.environ.get("GPFIT_EIGTOP_BASIS", "subspace")
 # per host thread (the reference's active-learning notebook fits and scores on two threads): the route the last
 # call of _stabilised_basis took, and (N, EIGVAL_TOL) -> "full" | "truncated", which of the two rank checks to try
 # first -- a hint only, so one thread's history never changes what another thread's fit costs

@@ -80,3 +80,37 @@ def test_subspace_solver_declines_an_ambiguous_count():
     w = torch.linalg.eigvalsh(K)
     if out is not None:      # rounding put it clearly on one side: then the count must agree with eigh's
         assert out[0].shape[0] == int((w > max(float(w[-1]) * tol, tol)).sum())
+
+
+def test_kept_eigenspace_without_a_dense_eigendecomposition():
+    """basis="subspace": the same sweeps, then the spectral projector of the k x k Rayleigh quotient matrix by a
+    Cayley transform and the Newton-Schulz sign iteration instead of its eigendecomposition -- same count as eigh's,
+    the same space to rounding, a dense K~_b = B^T K B whose eigenvalues are the kept ones, and a basis that depends on
+    the space alone (two different block sizes give the same columns)."""
+    n, tol = 900, 1e-4
+    K, lam, Q = kernel_like_matrix(n)
+    K = (K + K.T) / 2
+    w, U = torch.linalg.eigh(K)
+    keep = w > max(float(w[-1]) * tol, tol)
+    outs = []
+    for k0 in (128, 160):
+        out = eigtop.top_eigenpairs(K, tol, cpu_matmul, cpu_cholesky, k0=k0, basis="subspace")
+        assert out is not None and out[0] is None and out[2]["route"] == "subspace" and out[2]["rr"] == 0
+        B, info = out[1], out[2]
+        nk = int(keep.sum())
+        assert B.shape == (n, nk) and info["n"] == nk
+        eye = torch.eye(nk, dtype=torch.float64)
+        P = U[:, keep].T @ B
+        assert float((P.T @ P - eye).abs().max()) < 1e-9 and float((B.T @ B - eye).abs().max()) < 1e-12
+        assert float(((torch.linalg.eigvalsh(info["K_tilde_b"]) - w[keep]).abs() / w[keep]).max()) < 1e-10
+        assert float((info["K_tilde_inv_b"] @ info["K_tilde_b"] - eye).abs().max()) < 1e-8
+        outs.append(B)
+    assert float((outs[0] - outs[1]).abs().max()) < 1e-6
+    # an eigenvalue on the threshold: the sign iteration cannot settle, the eigenpair route takes over (and may decline too)
+    g = torch.Generator().manual_seed(2)
+    Qm, _ = torch.linalg.qr(torch.randn(600, 600, dtype=torch.float64, generator=g))
+    lam = 1e4 * (1.0 + torch.arange(600, dtype=torch.float64)) ** -2.0 + 1e-3
+    lam[40] = float(lam[0]) * 1e-3 * (1 + 1e-14)
+    Km = (Qm * lam) @ Qm.T
+    out = eigtop.top_eigenpairs((Km + Km.T) / 2, 1e-3, cpu_matmul, cpu_cholesky, k0=128, max_sweeps=24, basis="subspace")
+    assert out is None or out[2].get("route") != "subspace"

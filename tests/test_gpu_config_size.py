@@ -72,7 +72,7 @@ def closure_inputs(gp, g, tol=None):
     return n_px, X, xt, r, B.contiguous(), m_b, V_b, route
 
 
-@pytest.mark.parametrize("name,route", [("g3_closure_trunc_N4096_d256.npz", "eigtop"),
+@pytest.mark.parametrize("name,route", [("g3_closure_trunc_N4096_d256.npz", "subspace"),
                                         ("g3_closure_sparse_N4096_nt2048_d256.npz", "eigh")])
 def test_fused_closures_at_config_size_match_the_reference(gp, name, route):
     """N = 4096, d = 256 at the reference's default tolerance (515 of 4096 / 534 of 2048 eigen-directions kept): the

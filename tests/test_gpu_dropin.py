@@ -802,8 +802,29 @@ def test_truncated_basis_without_full_eigh(gp):
     assert bool((vecs.abs().max(0).values == vecs.max(0).values).all())   # sign convention
     again = eigtop.top_eigenpairs(K, gp.EIGVAL_TOL, gp.matmul, gp.cholesky)
     assert torch.equal(again[0], vals) and torch.equal(again[1], vecs)
-    eigvecs, B, Kb, Kib = gp._stabilised_basis(K)
-    assert torch.equal(B, vecs) and torch.equal(torch.diagonal(Kb), vals)
+    old_basis = gp.EIGTOP_BASIS
+    try:
+        gp.EIGTOP_BASIS = "eigenvectors"
+        eigvecs, B, Kb, Kib = gp._stabilised_basis(K)
+        assert gp._BASIS.route == "eigtop" and torch.equal(B, vecs) and torch.equal(torch.diagonal(Kb), vals)
+        # the default: the kept EIGENSPACE without any dense eigendecomposition (eigtop._kept_subspace: Cayley transform +
+        # Newton-Schulz sign iteration on the k x k Rayleigh quotient matrix, canonical basis by CholeskyQR2) -- same count,
+        # same space, K~_b = B^T K~ B dense with the kept eigenvalues as ITS eigenvalues, and the same bits twice
+        gp.EIGTOP_BASIS = "subspace"
+        _, Bs, Kbs, Kibs = gp._stabilised_basis(K)
+        assert gp._BASIS.route == "subspace" and Bs.shape == vecs.shape
+        Ps = U[:, keep].T @ Bs
+        assert float((Ps.T @ Ps - eye).abs().max()) < 1e-10 and float((Bs.T @ Bs - eye).abs().max()) < 1e-12
+        assert float(((torch.linalg.eigvalsh(Kbs) - w[keep]).abs() / w[keep]).max()) < 1e-11
+        assert float((Kbs - Bs.T @ K @ Bs).abs().max()) < 1e-12 * float(w[-1])
+        assert float((Kibs @ Kbs - eye).abs().max()) < 1e-9
+        _, Bs2, Kbs2, _ = gp._stabilised_basis(K, route="subspace")
+        assert torch.equal(Bs2, Bs) and torch.equal(Kbs2, Kbs)
+        # ... and the basis is a function of the SPACE, not of the block it was found in: another block size, same columns
+        _, B896, info896 = eigtop.top_eigenpairs(K, gp.EIGVAL_TOL, gp.matmul, gp.cholesky, k0=896, basis="subspace")
+        assert info896["route"] == "subspace" and float((B896 - Bs).abs().max()) < 1e-7
+    finally:
+        gp.EIGTOP_BASIS = old_basis
     # a rule that keeps more than a third of the spectrum is not a truncation problem: the solver declines
     assert eigtop.top_eigenpairs(K, 1e-6, gp.matmul, gp.cholesky, max_sweeps=16) is None
 
@@ -843,8 +864,8 @@ def test_vargp_with_the_subspace_basis_tracks_the_eigh_route(gp):
     """A whole fit at the reference's default tolerance at N = 4096 (about 520 of 4096 directions kept, the
     count moving with theta from one EM iteration to the next), once with the kept eigenpairs from the
     subspace solver and once with torch.linalg.eigh forced: same kept counts, log-marginal track to 1e-8, final
-    theta to 1e-7, predictions to 1e-7 (eigenvector signs differ between the two routes; nothing downstream
-    depends on them)."""
+    theta to 1e-7, predictions to 1e-7 (the subspace solver's B is an orthonormal basis of the kept eigenspace, not
+    its eigenvectors; nothing downstream depends on which basis of that space it is)."""
     N, d = 4096, 256
     dev = torch.device("cuda:0")
     X = T(syn.stimuli(N, d)).to(dev)
@@ -878,8 +899,8 @@ def test_vargp_with_the_subspace_basis_tracks_the_eigh_route(gp):
     b, Rb, Rb1 = run(True)
     assert a["B"].shape == b["B"].shape and 100 < a["B"].shape[1] < N // 4
     # the route that built each tracked basis is part of the model ...
-    assert a["basis_route"] == "eigtop" and b["basis_route"] == "eigh"
-    assert set(a["values_track"]["variation_par_track"]["basis_route"]) == {"eigtop"}
+    assert a["basis_route"] == "subspace" and b["basis_route"] == "eigh"
+    assert set(a["values_track"]["variation_par_track"]["basis_route"]) == {"subspace"}
     assert set(b["values_track"]["variation_par_track"]["basis_route"]) == {"eigh"}
     # ... and test(at_iteration) follows it whatever the process-wide setting says: the eigh-fitted model evaluated
     # with the subspace solver enabled still goes through eigh (Rb1 above was computed with it forced; same bits)
