@@ -19,6 +19,9 @@ LIBNAME = "libgpfit_mi355x.so"
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
          "-Wno-unused-result", "-I" + os.path.join(os.path.dirname(PKG), "include"), "-I" + CSRC]
+# development builds only (e.g. GPFIT_EXTRA_FLAGS=-DGPFIT_DEV: timing experiments that give wrong results by design);
+# part of the digest, so the next ordinary build replaces such a library
+FLAGS += os.environ.get("GPFIT_EXTRA_FLAGS", "").split()
 
 
 def _digest():

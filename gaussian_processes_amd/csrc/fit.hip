@@ -403,7 +403,15 @@ int potrf_lockstep(const CholBatchT<R>& B, int r0, int n, uint32_t need, hipStre
                   walks()[0], B.ws, B.sk_ws));
   // look-ahead of the inverse merge's first product on the side stream (as potrf_rec)
   hipEvent_t joined = nullptr;
-  if (need && B.ctx && B.side_min > 0 && n >= B.side_min && B.ctx->side[B.chain]) {
+#ifdef GPFIT_DEV
+  // timing experiment (wrong results by design): what the unit would cost if the first product of every inverse
+  // merge of a block of at least this size were hidden completely
+  static const int dev_skip_tmp = getenv("GPFIT_DEV_SKIP_TMP") ? atoi(getenv("GPFIT_DEV_SKIP_TMP")) : 0;
+  const bool skip_tmp = dev_skip_tmp > 0 && n >= dev_skip_tmp;
+#else
+  const bool skip_tmp = false;
+#endif
+  if (need && !skip_tmp && B.ctx && B.side_min > 0 && n >= B.side_min && B.ctx->side[B.chain]) {
     gpfit_ctx* c = B.ctx;
     auto next_event = [&]() {
       auto& pool = c->side_ev[B.chain];
@@ -427,7 +435,7 @@ int potrf_lockstep(const CholBatchT<R>& B, int r0, int n, uint32_t need, hipStre
   // A22 -= L21 L21^T.  On the latency-bound levels the first product of the inverse merge, L21 L11^-1 (it needs
   // L21 and L11^-1 only), rides in the same launch: one launch boundary less per node of the recursion.
   bool merged = false;
-  if (need && !joined) {
+  if (need && !joined && !skip_tmp) {
     static const bool no_batch = getenv("GPFIT_NO_BATCH") != nullptr;
     const GemmArgsT<R> g2 = batch_args<R>(B, all, 0, 0, n2, n2, n1, -1.0, B.L, off(r1, r0), B.L, off(r1, r0), 1.0, B.A, off(r1, r1),
                                           1, 0, 0, 0);
@@ -448,7 +456,7 @@ int potrf_lockstep(const CholBatchT<R>& B, int r0, int n, uint32_t need, hipStre
   GP_TRY(potrf_lockstep<R>(B, r1, n2, need, s));
   if (need) {
     if (joined) GP_HIP(hipStreamWaitEvent(s, joined, 0));
-    else if (!merged)
+    else if (!merged && !skip_tmp)
       GP_TRY(bgemm<R>(B, s, need, 0, 1, n2, n1, n1, 1.0, B.L, off(r1, r0), B.Li, off(r0, r0), 0.0, B.Tmp, off(r1, r0), 0, 0,
                       1, walks()[1], B.ws, B.sk_ws));
     GP_TRY(bgemm<R>(B, s, need, 0, 1, n2, n1, n2, -1.0, B.Li, off(r1, r1), B.Tmp, off(r1, r0), 0.0, B.Li, off(r1, r0), 0, 1, 0,
