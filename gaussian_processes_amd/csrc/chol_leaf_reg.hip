@@ -44,9 +44,12 @@ namespace gpfit {
 // wave `owner` / wave 0 at the phase boundaries of every panel (never compiled into the library)
 #ifdef GPFIT_LEAF_STAMPS
 __device__ long long g_leaf_stamps[9 * 8];
+__device__ long long g_leaf_wave_end[8 * 4];     // end of the update pass (3) per panel and tile wave
 #define LEAF_STAMP(kb, ph) do { if ((threadIdx.x & 63) == 0) g_leaf_stamps[(kb) * 8 + (ph)] = (long long)__builtin_readcyclecounter(); } while (0)
+#define LEAF_WAVE_END(kb, w) do { if ((threadIdx.x & 63) == 0) g_leaf_wave_end[(kb) * 4 + (w)] = (long long)__builtin_readcyclecounter(); } while (0)
 #else
 #define LEAF_STAMP(kb, ph) do { } while (0)
+#define LEAF_WAVE_END(kb, w) do { } while (0)
 #endif
 
 // Workgroup barrier / intra-wave LDS ordering that wait for LDS traffic only.  __syncthreads() and
@@ -78,7 +81,9 @@ __device__ __forceinline__ void rl_rsqrt_sqrt(double p, double& rinv, double& ro
   double y = __builtin_amdgcn_rsq(p);
   const double hp = 0.5 * p;
   y = y * fma(-hp * y, y, 1.5);
+#ifdef GPFIT_LEAF_TWO_NEWTON
   y = y * fma(-hp * y, y, 1.5);
+#endif
   double d = p * y;
   d = fma(fma(-d, d, p), 0.5 * y, d);
   rinv = y;
@@ -180,14 +185,134 @@ __device__ __forceinline__ void static_for_inv(R (&yh)[16], R m) {
   }
 }
 
-// The panel loop is a real loop and the wave index a run-time value: the code is executed eight
-// times and stays in the instruction cache.  (A fully unrolled, per-wave specialised version of
-// this kernel -- 100 KiB of straight-line code -- spent 83 % of its wave cycles waiting for
-// instruction fetches: 3.8 k instructions per wave in 150 k cycles.)  Register indices stay static
-// because the nine tile slots of a wave are walked by an unrolled loop whose body branches on
-// wave-uniform run-time conditions, and the one register operand that would need a run-time index
-// -- X[kb, j] as the B operand of the Y updates -- is copied to a fixed tile (xrow) when it is
-// produced: the slots of a column are walked in row order, so its row-kb slot comes first.
+// Column ownership of the four tile waves.  Tile column j has 8 - j tiles; a wave owns two whole columns (the inverse
+// needs the tiles of a column together).  Wave 0 shares its SIMD with the pivot wave, whose VALU-bound chains outrank
+// it (s_setprio): with nine tiles per wave it finished its update pass 2 k cycles behind the other three, so it
+// owns the two shortest columns (3 tiles) and the other waves 11 tiles each.
+constexpr int RL_SLOTS = 11;
+__host__ __device__ constexpr int rl_col_a(int w) { return w == 0 ? 6 : w - 1; }          // 6, 0, 1, 2
+__host__ __device__ constexpr int rl_col_b(int w) { return w == 0 ? 7 : 6 - w; }          // 7, 5, 4, 3
+__host__ __device__ constexpr int rl_nslots(int w) { return (8 - rl_col_a(w)) + (8 - rl_col_b(w)); }   // 3, 11, 11, 11
+__host__ __device__ constexpr int rl_slot_i(int w, int t) { return t < 8 - rl_col_a(w) ? rl_col_a(w) + t : rl_col_b(w) + (t - (8 - rl_col_a(w))); }
+__host__ __device__ constexpr int rl_slot_j(int w, int t) { return t < 8 - rl_col_a(w) ? rl_col_a(w) : rl_col_b(w); }
+
+// Step (3) of a panel for tile wave W, specialised per wave: the tile coordinates of the nine slots are compile-time
+// constants (LDS offsets become immediates, the column fragment of a slot is known, every guard compares the panel
+// counter with a constant), while the panel loop around it stays rolled -- four copies of this pass instead of one
+// generic copy whose guards and addresses are re-derived from the wave index for every slot and panel (measured on the
+// generic copy: 3.8 k cycles per panel with only two active slots, 5.5-7.5 k with all of them, for at most 2.3 k cycles
+// of matrix-pipe issue).  All LDS operands are requested up front and waited for once.
+template <typename R, int W>
+__device__ __forceinline__ void leaf_update_pass(typename Real<R>::acc_t (&acc)[RL_SLOTS], typename Real<R>::acc_t& xrow,
+                                                 const R* __restrict__ P, const R* __restrict__ Dv, R* __restrict__ RawN,
+                                                 R* __restrict__ Dg0, R* __restrict__ Dg1, int kb, const int (&kr)[4], int fr) {
+  using Acc = typename Real<R>::acc_t;
+  constexpr int NSL = rl_nslots(W), CA = rl_col_a(W), CB = rl_col_b(W);
+  const int nx = kb + 1;
+  // the row fragment L[i, kb] of slot t + 1 is requested before the products of slot t (two fragments in flight); the
+  // column fragments and Dinv, shared by all slots, once at the top
+  R fa[2][4], fbA[4], fbB[4], dd[4];
+  Acc dvt;
+  auto row_frag = [&](int t, R (&f)[4]) {
+    const int i = rl_slot_i(W, t);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) f[r] = P[(16 * i + fr) * RPS + kr[r]];          // rows <= kb: stale, never used
+  };
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    fbA[r] = P[(16 * CA + fr) * RPS + kr[r]];
+    fbB[r] = P[(16 * CB + fr) * RPS + kr[r]];
+    dd[r] = Dv[fr * RPS + kr[r]];
+    dvt[r] = Dv[kr[r] * RPS + fr];
+  }
+  row_frag(0, fa[0]);
+#pragma unroll
+  for (int t = 0; t < NSL; ++t) {
+    const int i = rl_slot_i(W, t), j = rl_slot_j(W, t);
+    Acc& a = acc[t];
+    if (t + 1 < NSL) row_frag(t + 1, fa[(t + 1) & 1]);
+    const R (&f)[4] = fa[t & 1];
+    if (j > kb) {
+      if (i == nx && j == nx) continue;   // the pivot wave took this tile over (mailbox of the previous panel)
+      // Schur complement  S[i, j] -= L[i, kb] L[j, kb]^T
+#pragma unroll
+      for (int r = 0; r < 4; ++r) a = Real<R>::mfma(-f[r], j == CA ? fbA[r] : fbB[r], a);
+      if (j == nx) {
+        // final through panel kb: a row of the raw column of the next panel
+#pragma unroll
+        for (int r = 0; r < 4; ++r) RawN[(16 * i + kr[r]) * RPS + fr] = a[r];
+      } else if (i == nx + 1 && j == nx + 1) {
+        // the diagonal tile of column kb + 2, final through panel kb: into the mailbox of the pivot wave
+        R* Dg = (j & 1) ? Dg1 : Dg0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Dg[kr[r] * RPS + fr] = a[r];
+      }
+    } else if (i == kb) {
+      // row kb of the inverse:  X[kb, kb] = Dinv,  X[kb, j] = -Dinv Y[kb, j]
+      Acc nxv;
+      if (j == kb) {
+        nxv = dvt;
+      } else {
+        nxv = acc_zero<R>();
+#pragma unroll
+        for (int r = 0; r < 4; ++r) nxv = Real<R>::mfma(-dd[r], a[r], nxv);
+      }
+      a = nxv;
+      xrow = nxv;
+    } else if (i > kb) {
+      // running sums of the rows still to come:  Y[i, j] += L[i, kb] X[kb, j]
+      Acc y = (j == kb) ? acc_zero<R>() : a;  // column kb held the raw panel until now
+#pragma unroll
+      for (int r = 0; r < 4; ++r) y = Real<R>::mfma(f[r], xrow[r], y);
+      a = y;
+    }
+    // nothing moves across a slot boundary: left to itself the scheduler hoists the row-fragment reads of ALL slots to
+    // the top of the pass (88 more registers live at once: spills)
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+// Prologue / epilogue of tile wave W (its tiles in, the raw column 0 and the first two diagonal tiles into LDS; the
+// finished rows of the inverse out): specialised per wave like the update pass.
+template <typename R, int W>
+__device__ __forceinline__ void leaf_load_tiles(typename Real<R>::acc_t (&acc)[RL_SLOTS], const R* __restrict__ A, int64_t lda,
+                                                R* __restrict__ Raw0, R* __restrict__ Dg0, R* __restrict__ Dg1,
+                                                const int (&kr)[4], int fr) {
+#pragma unroll
+  for (int t = 0; t < RL_SLOTS; ++t) {
+    if (t >= rl_nslots(W)) { acc[t] = acc_zero<R>(); continue; }
+    const int i = rl_slot_i(W, t), j = rl_slot_j(W, t);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[t][r] = A[(int64_t)(16 * i + kr[r]) * lda + 16 * j + fr];
+    // prologue of the pipeline: raw column 0 and the diagonal tiles of columns 0 and 1
+    if (j == 0 && i > 0) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) Raw0[(16 * i + kr[r]) * RPS + fr] = acc[t][r];
+    }
+    if (i == j && j <= 1) {
+      R* Dg = j ? Dg1 : Dg0;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) Dg[kr[r] * RPS + fr] = acc[t][r];
+    }
+  }
+}
+template <typename R, int W>
+__device__ __forceinline__ void leaf_store_inverse(const typename Real<R>::acc_t (&acc)[RL_SLOTS], R* __restrict__ Linv,
+                                                   int64_t ldi, const int (&kr)[4], int fr) {
+#pragma unroll
+  for (int t = 0; t < rl_nslots(W); ++t) {
+    const int i = rl_slot_i(W, t), j = rl_slot_j(W, t);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Linv[(int64_t)(16 * i + kr[r]) * ldi + 16 * j + fr] = acc[t][r];
+  }
+}
+
+// The panel loop is a real loop: the code is executed eight times and stays in the instruction cache.  (A fully
+// unrolled, per-wave specialised version of this kernel -- 100 KiB of straight-line code -- spent 83 % of its wave
+// cycles waiting for instruction fetches.)  Round 4: the passes that walk a wave's tile slots ARE specialised per wave
+// (leaf_update_pass and the two helpers above, four copies each, selected by one switch on the wave index) while the
+// panel loop stays rolled, and the pivot wave has a loop of its own: its path never touches the accumulators, so their
+// 88 registers and the 64 of the pivot sweep (v, yh) overlay instead of adding up.
 // One workgroup per block of the batch (LeafBatchT, kernels.h): blocks of several factorisations that
 // have reached a leaf together (the K~ and V chains of a unit, the chains of several units) share the launch.
 template <typename R>
@@ -212,140 +337,79 @@ __global__ __launch_bounds__(RL_THREADS, 2) void chol_leaf_reg_kernel(LeafBatchT
   __shared__ __attribute__((aligned(16))) R Sx[16 * RPS];        // scratch of the pivot wave (layout changes)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const bool pivot_wave = wave == 4;
   const int fr = lane & 15;
   int kr[4];  // k index (= C/D row) this lane carries in register r
 #pragma unroll
   for (int r = 0; r < 4; ++r) kr[r] = Real<R>::crow(lane, r);
-  // slot t of wave w: t < n1 -> tile (w + t, w), else tile (7 - w + t - n1, 7 - w)
-  const int tw = pivot_wave ? 0 : wave;   // (the pivot wave owns no tiles; its slots are never touched)
-  const int n1w = 8 - tw;
-  auto slot_iw = [&](int t) { return t < n1w ? tw + t : (7 - tw) + (t - n1w); };
-  auto slot_jw = [&](int t) { return t < n1w ? tw : 7 - tw; };
 
-  Acc acc[9];
-  if (!pivot_wave) {
-#pragma unroll
-    for (int t = 0; t < 9; ++t) {
-      const int i = slot_iw(t), j = slot_jw(t);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) acc[t][r] = A[(int64_t)(16 * i + kr[r]) * lda + 16 * j + fr];
-      // prologue of the pipeline: raw column 0 and the diagonal tiles of columns 0 and 1
-      if (j == 0 && i > 0) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) Rawb[0][(16 * i + kr[r]) * RPS + fr] = acc[t][r];
-      }
-      if (i == j && j <= 1) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) Dgb[j][kr[r] * RPS + fr] = acc[t][r];
-      }
-    }
-    // strict upper tiles of both outputs are zero (the callers read whole 128-blocks)
-    for (int e = tid; e < 28 * 64; e += RL_TILE_THREADS) {
-      const int tix = e >> 6, q = e & 63;
-      int ti = 0, rem = tix;  // tix -> (ti, tj) with tj > ti: rows 0..6 hold 7, 6, .. 1 tiles
-      while (rem >= 7 - ti) { rem -= 7 - ti; ++ti; }
-      const int tj = ti + 1 + rem;
-      const int row = 16 * ti + (q >> 2), col = 16 * tj + 4 * (q & 3);
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        L[(int64_t)row * ldl + col + c] = (R)0;
-        Linv[(int64_t)row * ldi + col + c] = (R)0;
-      }
-    }
-  } else {
-#pragma unroll
-    for (int t = 0; t < 9; ++t) acc[t] = acc_zero<R>();
-    // the pivot chains are the critical path of the kernel and VALU-issue bound; the wave shares its SIMD with a
+  if (wave == 4) {
+    // ================= the pivot wave: the pivot chains, one panel ahead of the tile waves =================
+    // the chains are the critical path of the kernel and VALU-issue bound; the wave shares its SIMD with a
     // tile wave whose updates would otherwise take every other issue slot (6.3 k instead of 3.9 k cycles per chain)
     __builtin_amdgcn_s_setprio(3);
-  }
-  LEAF_STAMP(8, 0);
-
-  // The pivot wave's part of a panel: factor the 16 x 16 block held row-major in Sx (a row per lane) and invert the
-  // factor by the same sweep; Dinv -> Dbuf[nx & 1], the rows of L -> memory.
-  auto pivot_block = [&](int nx, int lane_o) {
-    R v[16], yh[16];
-    {
-      const R* row = Sx + (lane & 15) * RPS;
+    LEAF_STAMP(8, 0);
+    // factor the 16 x 16 block held row-major in Sx (a row per lane) and invert the factor by the same sweep;
+    // Dinv -> Dbuf[nx & 1], the rows of L -> memory
+    auto pivot_block = [&](int nx, int lane_o) {
+      R v[16], yh[16];
+      {
+        const R* row = Sx + (lane & 15) * RPS;
 #pragma unroll
-      for (int q = 0; q < 16 / EPC; ++q) {
-        const V w = *reinterpret_cast<const V*>(row + EPC * q);
+        for (int q = 0; q < 16 / EPC; ++q) {
+          const V w = *reinterpret_cast<const V*>(row + EPC * q);
 #pragma unroll
-        for (int e = 0; e < EPC; ++e) v[EPC * q + e] = (lane < 16) ? w[e] : (R)0;
-      }
-    }
-#pragma unroll
-    for (int j = 0; j < 16; ++j) yh[j] = (j == lane_o) ? (R)1 : (R)0;
-    int first_bad = 0;
-    R myr = (R)0;  // lane k keeps 1 / L_kk
-    LEAF_STAMP(nx, 1);
-    static_for_pivots<R, 0>(v, yh, myr, first_bad, lane, 16 * nx);
-    LEAF_STAMP(nx, 2);
-    if (lane == 0 && first_bad != 0) atomicCAS(info, 0, info_base + first_bad);
-    if (lane < 16) {
-      R* drow = Dbuf[nx & 1] + lane * RPS;
-      R* grow = L + (int64_t)(16 * nx + lane) * ldl + 16 * nx;
-#pragma unroll
-      for (int q = 0; q < 16 / EPC; ++q) {
-        V lv, dv;
-#pragma unroll
-        for (int e = 0; e < EPC; ++e) {
-          const int j = EPC * q + e;
-          lv[e] = (j <= lane) ? v[j] : (R)0;
-          dv[e] = yh[j] * myr;                       // zero above the diagonal by construction
+          for (int e = 0; e < EPC; ++e) v[EPC * q + e] = (lane < 16) ? w[e] : (R)0;
         }
-        *reinterpret_cast<V*>(drow + EPC * q) = dv;      // (the diagonal rows of L are never read from LDS --
-        *reinterpret_cast<V*>(grow + EPC * q) = lv;      //  only their inverse is -- and go to memory only)
       }
-    }
-    LEAF_STAMP(nx, 3);
-  };
-
-  lds_barrier();   // B0: raw column 0 and the first two diagonal tiles are in LDS
-  if (pivot_wave) {
-    // column 0: nothing to update, the diagonal tile goes from the mailbox to the row-per-lane layout
-    int lane_o = lane;
-    asm volatile("" : "+v"(lane_o));
 #pragma unroll
-    for (int r = 0; r < 4; ++r) Sx[kr[r] * RPS + fr] = Dgb[0][kr[r] * RPS + fr];
-    lds_fence();
-    pivot_block(0, lane_o);
-  }
-
-  // Software pipeline over the panels with a dedicated pivot wave, synchronised by workgroup barriers only.
-  // Panel j = 0 .. 7, after barrier B1(j) (Dinv of panel j, raw column j and the diagonal tile of column j + 1,
-  // final through panel j - 1, are in LDS):
-  //   tile waves:  (2) the rows below, L[i, j] = S[i, j] Dinv^T          [B2(j)]
-  //                (3) update their tiles from panel j; the owner of column j + 1 puts its rows below the diagonal
-  //                    into the raw buffer of panel j + 1, the owner of column j + 2 its diagonal tile (final
-  //                    through panel j) into the mailbox                                         [B1(j + 1)]
-  //   pivot wave:  its OWN copy of L[j + 1, j] from the raw column and Dinv (not waiting for (2)), the last Schur
-  //                update of the diagonal tile of column j + 1 from it                          [B2(j)]
-  //                the pivot chain of panel j + 1 -- a quarter of a panel's time, one wave's work -- beside (3)
-  //                                                                                              [B1(j + 1)]
-  // so the chain  Dinv(j) -> L[j + 1, j] -> S[j + 1, j + 1] -> pivots(j + 1)  never leaves the pivot wave and waits
-  // for nobody; two barriers per panel, no flags.
-  Acc xrow = acc_zero<R>();  // X[kb, j] of the column being walked (its row-kb slot comes before its later rows)
+      for (int j = 0; j < 16; ++j) yh[j] = (j == lane_o) ? (R)1 : (R)0;
+      int first_bad = 0;
+      R myr = (R)0;  // lane k keeps 1 / L_kk
+      LEAF_STAMP(nx, 1);
+      static_for_pivots<R, 0>(v, yh, myr, first_bad, lane, 16 * nx);
+      LEAF_STAMP(nx, 2);
+      if (lane == 0 && first_bad != 0) atomicCAS(info, 0, info_base + first_bad);
+      if (lane < 16) {
+        R* drow = Dbuf[nx & 1] + lane * RPS;
+        R* grow = L + (int64_t)(16 * nx + lane) * ldl + 16 * nx;
+#pragma unroll
+        for (int q = 0; q < 16 / EPC; ++q) {
+          V lv, dv;
+#pragma unroll
+          for (int e = 0; e < EPC; ++e) {
+            const int j = EPC * q + e;
+            lv[e] = (j <= lane) ? v[j] : (R)0;
+            dv[e] = yh[j] * myr;                       // zero above the diagonal by construction
+          }
+          *reinterpret_cast<V*>(drow + EPC * q) = dv;      // (the diagonal rows of L are never read from LDS --
+          *reinterpret_cast<V*>(grow + EPC * q) = lv;      //  only their inverse is -- and go to memory only)
+        }
+      }
+      LEAF_STAMP(nx, 3);
+    };
+    {
+      // column 0: nothing to update -- the wave fetches the diagonal tile itself and runs the first chain while the
+      // tile waves are still loading theirs (their prologue is 9 k cycles, the chain 4 k)
+      int lane_o = lane;
+      asm volatile("" : "+v"(lane_o));
+      if (lane < 16) {
+        const R* arow = A + (int64_t)lane * lda;
+        R* srow = Sx + lane * RPS;
+#pragma unroll
+        for (int q = 0; q < 16 / EPC; ++q) *reinterpret_cast<V*>(srow + EPC * q) = *reinterpret_cast<const V*>(arow + EPC * q);
+      }
+      lds_fence();
+      pivot_block(0, lane_o);
+    }
+    lds_barrier();   // B0: raw column 0 and the diagonal tile of column 1 are in LDS (tile waves), Dinv of panel 0 (here)
 #pragma unroll 1
-  for (int kb = 0; kb < 8; ++kb) {
-    // The tile coordinates of the slots depend on the wave only; left alone, the compiler hoists every
-    // LDS offset and store address of every slot out of this loop (100+ VGPRs, spilled to scratch).
-    // Re-deriving them from an opaque copy of the wave index each iteration costs one add per access.
-    int wv = tw, lane_o = lane;
-    asm volatile("" : "+s"(wv));
-    asm volatile("" : "+v"(lane_o));
-    const int n1 = 8 - wv;
-    auto slot_i = [&](int t) { return t < n1 ? wv + t : (7 - wv) + (t - n1); };
-    auto slot_j = [&](int t) { return t < n1 ? wv : 7 - wv; };
-    const int nx = kb + 1;
-    const R* const Raw = Rawb[0];                        // raw column kb
-    R* const P = Lpb[0];                                 // L rows of panel kb
-    const R* const Dv = Dbuf[kb & 1];                    // Dinv of panel kb
-    R* const RawN = Rawb[0];                             // raw column kb + 1 (assembled behind B2(kb))
-
-    lds_barrier();   // B1(kb)
-    if (pivot_wave) {
+    for (int kb = 0; kb < 8; ++kb) {
+      int lane_o = lane;
+      asm volatile("" : "+v"(lane_o));
+      const int nx = kb + 1;
+      const R* const Raw = Rawb[0];                        // raw column kb
+      const R* const Dv = Dbuf[kb & 1];                    // Dinv of panel kb
+      lds_barrier();   // B1(kb)
       LEAF_STAMP(kb, 4);
       if (nx < 8) {
         // L[nx, kb] = S[nx, kb] Dinv^T  (the same product the tile waves form in (2): same bits)
@@ -375,10 +439,51 @@ __global__ __launch_bounds__(RL_THREADS, 2) void chol_leaf_reg_kernel(LeafBatchT
         LEAF_STAMP(nx, 0);
         pivot_block(nx, lane_o);
       }
-      continue;
     }
+    return;
+  }
 
-    // ---- tile waves ----
+  // ================= the four tile waves =================
+  Acc acc[RL_SLOTS];
+  switch (wave) {
+    case 0: leaf_load_tiles<R, 0>(acc, A, lda, Rawb[0], Dgb[0], Dgb[1], kr, fr); break;
+    case 1: leaf_load_tiles<R, 1>(acc, A, lda, Rawb[0], Dgb[0], Dgb[1], kr, fr); break;
+    case 2: leaf_load_tiles<R, 2>(acc, A, lda, Rawb[0], Dgb[0], Dgb[1], kr, fr); break;
+    default: leaf_load_tiles<R, 3>(acc, A, lda, Rawb[0], Dgb[0], Dgb[1], kr, fr); break;
+  }
+  lds_barrier();   // B0
+
+  // Software pipeline over the panels with a dedicated pivot wave, synchronised by workgroup barriers only.
+  // Panel j = 0 .. 7, after barrier B1(j) (Dinv of panel j, raw column j and the diagonal tile of column j + 1,
+  // final through panel j - 1, are in LDS):
+  //   tile waves:  (2) the rows below, L[i, j] = S[i, j] Dinv^T          [B2(j)]
+  //                (3) update their tiles from panel j; the owner of column j + 1 puts its rows below the diagonal
+  //                    into the raw buffer of panel j + 1, the owner of column j + 2 its diagonal tile (final
+  //                    through panel j) into the mailbox                                         [B1(j + 1)]
+  //   pivot wave:  its OWN copy of L[j + 1, j] from the raw column and Dinv (not waiting for (2)), the last Schur
+  //                update of the diagonal tile of column j + 1 from it                          [B2(j)]
+  //                the pivot chain of panel j + 1 -- a quarter of a panel's time, one wave's work -- beside (3)
+  //                                                                                              [B1(j + 1)]
+  // so the chain  Dinv(j) -> L[j + 1, j] -> S[j + 1, j + 1] -> pivots(j + 1)  never leaves the pivot wave and waits
+  // for nobody; two barriers per panel, no flags.
+  Acc xrow = acc_zero<R>();  // X[kb, j] of the column being walked (its row-kb slot comes before its later rows)
+#pragma unroll 1
+  for (int kb = 0; kb < 8; ++kb) {
+    // Left alone, the compiler hoists every LDS offset and store address of every slot of all four specialised
+    // passes out of this loop (256 VGPRs and spills).  Re-deriving the lane's coordinates from an opaque copy of the
+    // lane index each iteration keeps them inside: one and / shift per use.
+    int lane_o = lane;
+    asm volatile("" : "+v"(lane_o));
+    const int fr = lane_o & 15;
+    int kr[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) kr[r] = Real<R>::crow(lane_o, r);
+    const R* const Raw = Rawb[0];                        // raw column kb
+    R* const P = Lpb[0];                                 // L rows of panel kb
+    const R* const Dv = Dbuf[kb & 1];                    // Dinv of panel kb
+    R* const RawN = Rawb[0];                             // raw column kb + 1 (assembled behind B2(kb))
+
+    lds_barrier();   // B1(kb)
     // ---- (2) rows below: L[i, kb] = S[i, kb] Dinv^T, tiles kb+1 .. 7 dealt to the tile waves
     {
       Acc s0 = acc_zero<R>(), s1 = acc_zero<R>();
@@ -416,59 +521,40 @@ __global__ __launch_bounds__(RL_THREADS, 2) void chol_leaf_reg_kernel(LeafBatchT
       }
     }
     lds_barrier();   // B2(kb): L[., kb] is in LDS
-    // ---- (3) every tile wave updates its tiles from panel kb
-#pragma unroll
-    for (int t = 0; t < 9; ++t) {
-      const int i = slot_i(t), j = slot_j(t);
-      Acc& a = acc[t];
-      if (j > kb) {
-        if (i == nx && j == nx) continue;   // the pivot wave took this tile over (mailbox of the previous panel)
-        // Schur complement  S[i, j] -= L[i, kb] L[j, kb]^T
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-          a = Real<R>::mfma(-P[(16 * i + fr) * RPS + kr[r]], P[(16 * j + fr) * RPS + kr[r]], a);
-        if (j == nx) {
-          // final through panel kb: a row of the raw column of the next panel
-#pragma unroll
-          for (int r = 0; r < 4; ++r) RawN[(16 * i + kr[r]) * RPS + fr] = a[r];
-        } else if (i == nx + 1 && j == nx + 1) {
-          // the diagonal tile of column kb + 2, final through panel kb: into the mailbox of the pivot wave
-#pragma unroll
-          for (int r = 0; r < 4; ++r) Dgb[j & 1][kr[r] * RPS + fr] = a[r];
-        }
-      } else if (i == kb) {
-        // row kb of the inverse:  X[kb, kb] = Dinv,  X[kb, j] = -Dinv Y[kb, j]
-        Acc nxv;
-        if (j == kb) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) nxv[r] = Dv[kr[r] * RPS + fr];
-        } else {
-          nxv = acc_zero<R>();
-#pragma unroll
-          for (int r = 0; r < 4; ++r) nxv = Real<R>::mfma(-Dv[fr * RPS + kr[r]], a[r], nxv);
-        }
-        a = nxv;
-        xrow = nxv;
-      } else if (i > kb) {
-        // running sums of the rows still to come:  Y[i, j] += L[i, kb] X[kb, j]
-        Acc y = (j == kb) ? acc_zero<R>() : a;  // column kb held the raw panel until now
-#pragma unroll
-        for (int r = 0; r < 4; ++r) y = Real<R>::mfma(P[(16 * i + fr) * RPS + kr[r]], xrow[r], y);
-        a = y;
-      }
+    // ---- (3) every tile wave updates its tiles from panel kb (leaf_update_pass, one specialisation per wave)
+    switch (wave) {
+      case 0: leaf_update_pass<R, 0>(acc, xrow, P, Dv, RawN, Dgb[0], Dgb[1], kb, kr, fr); break;
+      case 1: leaf_update_pass<R, 1>(acc, xrow, P, Dv, RawN, Dgb[0], Dgb[1], kb, kr, fr); break;
+      case 2: leaf_update_pass<R, 2>(acc, xrow, P, Dv, RawN, Dgb[0], Dgb[1], kb, kr, fr); break;
+      default: leaf_update_pass<R, 3>(acc, xrow, P, Dv, RawN, Dgb[0], Dgb[1], kb, kr, fr); break;
     }
-    if (wave == 0) LEAF_STAMP(kb, 6);
+    if (wave == 0) {
+      // wave 0 owns three tiles and is done with its pass 1.5 k cycles before the others: it writes the zeros of the
+      // strict upper tiles of tile row kb of both outputs (the callers read whole 128-blocks), 28 tiles over the panels
+      const int row = 16 * kb + (lane_o >> 2), cq = 4 * (lane_o & 3);
+      V zero2;
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) zero2[e] = (R)0;
+      for (int tj = kb + 1; tj < 8; ++tj) {
+        R* lrow = L + (int64_t)row * ldl + 16 * tj + cq;
+        R* irow = Linv + (int64_t)row * ldi + 16 * tj + cq;
+#pragma unroll
+        for (int q = 0; q < 4 / EPC; ++q) {
+          *reinterpret_cast<V*>(lrow + EPC * q) = zero2;
+          *reinterpret_cast<V*>(irow + EPC * q) = zero2;
+        }
+      }
+      LEAF_STAMP(kb, 6);
+    }
+    LEAF_WAVE_END(kb, wave);
   }
 
-  // all rows of the inverse are final (store addresses derived here, not kept live through the loop)
-  if (pivot_wave) return;
-  int wv2 = wave;
-  asm volatile("" : "+s"(wv2));
-#pragma unroll
-  for (int t = 0; t < 9; ++t) {
-    const int i = t < 8 - wv2 ? wv2 + t : (7 - wv2) + (t - (8 - wv2)), j = t < 8 - wv2 ? wv2 : 7 - wv2;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) Linv[(int64_t)(16 * i + kr[r]) * ldi + 16 * j + fr] = acc[t][r];
+  // all rows of the inverse are final
+  switch (wave) {
+    case 0: leaf_store_inverse<R, 0>(acc, Linv, ldi, kr, fr); break;
+    case 1: leaf_store_inverse<R, 1>(acc, Linv, ldi, kr, fr); break;
+    case 2: leaf_store_inverse<R, 2>(acc, Linv, ldi, kr, fr); break;
+    default: leaf_store_inverse<R, 3>(acc, Linv, ldi, kr, fr); break;
   }
   LEAF_STAMP(8, 1);
 }

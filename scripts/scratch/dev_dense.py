@@ -1,7 +1,7 @@
 """One dense 8192^3 fp64 GEMM (NT) + syrk + R-shape: target of PMC passes."""
 import os, sys
 import torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from gaussian_processes_amd import _lib
 lib = _lib.load()
 dev = torch.device("cuda:0")

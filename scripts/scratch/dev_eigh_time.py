@@ -1,5 +1,5 @@
 import os, sys, time, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from gaussian_processes_amd import utils as gp, synthetic as syn
 dev = torch.device("cuda")
 lower, upper = syn.limits()

@@ -1,6 +1,6 @@
 """Block subspace iteration (gaussian_processes_amd/eigtop.py) against torch.linalg.eigh on the bench kernel matrix."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from gaussian_processes_amd import utils as gp, synthetic as syn, eigtop
 import bench

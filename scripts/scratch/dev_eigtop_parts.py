@@ -1,6 +1,6 @@
 """Time split of eigtop.top_eigenpairs on the bench kernel matrix (wraps the primitives with synchronised timers)."""
 import os, sys, time, collections
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from gaussian_processes_amd import utils as gp, synthetic as syn, eigtop
 import bench

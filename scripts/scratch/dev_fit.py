@@ -1,7 +1,7 @@
 """Dev check on the GPU box: gpfit_fit_eval vs the CPU oracle (Cholesky formulation)."""
 import ctypes, os, sys, time
 import numpy as np, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from gaussian_processes_amd import _lib, synthetic as syn
 from oracle import gp_oracle as orc
 lib = _lib.load()

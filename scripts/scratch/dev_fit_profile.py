@@ -1,6 +1,6 @@
 """cProfile of a whole varGP fit (examples/one_cell_fit.py settings) -- where the host time goes."""
 import cProfile, io, os, pstats, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 sys.argv = ["one_cell_fit.py"] + sys.argv[1:]
 import runpy
 pr = cProfile.Profile()

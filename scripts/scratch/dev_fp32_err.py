@@ -1,7 +1,7 @@
 """Where does the fp32 instance's loss error come from?  (a) rounding K~ and V to fp32 only, all
 arithmetic fp64; (b) the fp32 instance.  Corner 448 of the theta lattice at N=8192."""
 import os, sys, numpy as np, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from gaussian_processes_amd import synthetic as syn, utils as gp
 from gaussian_processes_amd.engine import GPFitEngine
 dev = torch.device("cuda:0")

@@ -1,7 +1,7 @@
 """Dev check on the GPU box: dgemm correctness (all layouts / tri flags / edges) + throughput."""
 import ctypes, os, sys, time
 import torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from gaussian_processes_amd.build import lib_path
 lib = ctypes.CDLL(lib_path())
 lib.gpfit_last_error.restype = ctypes.c_char_p

@@ -4,7 +4,7 @@ s_memrealtime stamps of the last T (B k-major) and Q launches -- median over wor
 HIP-event duration of those launches.  MI355X_MICROARCH.md 'DVFS give-back' item 6."""
 import ctypes, os, sys, time
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import torch
 from gaussian_processes_amd import _lib

@@ -2,7 +2,7 @@
 scripts/scratch/dev_gemm_abl.hip and with the in-fit durations of the kernel trace)."""
 import ctypes, os, sys
 import torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from gaussian_processes_amd import _lib
 lib = _lib.load(); dev = torch.device("cuda:0")
 n = 8192

@@ -2,7 +2,7 @@
     python scripts/scratch/dev_group.py [N] [d] [units] [group] [mode: f64|mixed] [reuse_V 0|1]"""
 import os, sys, time
 import torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from gaussian_processes_amd import synthetic as syn, multi
 from gaussian_processes_amd.engine import GPFitEngine, fit_eval_group
 import bench

@@ -1,7 +1,7 @@
 """How much does a concurrent long GEMM on another stream slow the latency-bound Cholesky chain?"""
 import ctypes, os, sys, time
 import numpy as np, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from gaussian_processes_amd import _lib, utils as gp, synthetic as syn
 lib = _lib.load(); dev = torch.device("cuda:0")
 n = 8192

@@ -2,7 +2,7 @@
 gpfit_fit_eval profile at N=8192 for phase ablations (GPFIT_LEAF_DBG)."""
 import ctypes, os, sys, time
 import torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from gaussian_processes_amd import synthetic as syn
 from gaussian_processes_amd.engine import GPFitEngine
 dev = torch.device("cuda:0")

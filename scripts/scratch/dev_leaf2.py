@@ -2,7 +2,7 @@
 and leaf timing through the profile counters.  GPFIT_LEAF_LDS=1 selects the old LDS-resident leaf."""
 import ctypes, os, sys, time
 import numpy as np, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from gaussian_processes_amd import utils as gp, synthetic as syn
 from gaussian_processes_amd.engine import GPFitEngine
 dev = torch.device("cuda:0")

@@ -4,7 +4,7 @@
 #ifndef NO_STAMPS
 #define GPFIT_LEAF_STAMPS 1
 #endif
-#include "../gaussian_processes_amd/csrc/chol_leaf_reg.hip"
+#include "../../gaussian_processes_amd/csrc/chol_leaf_reg.hip"
 #include <vector>
 #include <cstdio>
 #include <cmath>
@@ -50,6 +50,12 @@ int main() {
     for (int ph = 0; ph < 7; ++ph) printf(" %s %.0f", names[ph], (double)st[kb * 8 + ph] - t0);
     printf("\n");
   }
+  long long we[32];
+  hipMemcpyFromSymbol(we, HIP_SYMBOL(gpfit::g_leaf_wave_end), sizeof(we));
+  for (int kb = 0; kb < 8; ++kb)
+    printf("panel %d: update pass of tile waves 0..3 ends %.0f %.0f %.0f %.0f after B2 (%.0f)\n", kb, (double)we[kb * 4] - (double)st[kb * 8 + 5],
+           (double)we[kb * 4 + 1] - (double)st[kb * 8 + 5], (double)we[kb * 4 + 2] - (double)st[kb * 8 + 5], (double)we[kb * 4 + 3] - (double)st[kb * 8 + 5],
+           (double)st[kb * 8 + 5] - t0);
   return 0;
 #endif
 }

@@ -2,7 +2,7 @@
 Prints ms/fit, phases and the hex of every output scalar (run under GPFIT_LOCKSTEP=0/1, GPFIT_NO_BATCH=1 and diff)."""
 import os, sys, time
 import numpy as np, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from gaussian_processes_amd import synthetic as syn
 from gaussian_processes_amd.engine import GPFitEngine
 import bench

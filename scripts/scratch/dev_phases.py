@@ -1,10 +1,10 @@
 """Phase timing of the headline unit (no profiler): python scripts/scratch/dev_phases.py [N] [d] [reps]"""
 import os, sys, time
 import numpy as np, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from gaussian_processes_amd import synthetic as syn
 from gaussian_processes_amd.engine import GPFitEngine
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import bench
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
 d = int(sys.argv[2]) if len(sys.argv) > 2 else 256

@@ -1,5 +1,5 @@
 import os, sys, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from gaussian_processes_amd import _lib
 lib = _lib.load(); dev = torch.device("cuda:0")
 scr = torch.empty(4096 * 256, dtype=torch.float64, device=dev)

@@ -1,7 +1,7 @@
 """cProfile of the whole varGP fit through the drop-in (where does the host time go?)."""
 import cProfile, contextlib, io, os, pstats, sys, warnings
 import numpy as np, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from gaussian_processes_amd import utils as gp, synthetic as syn
 N, d = int(sys.argv[1]) if len(sys.argv) > 1 else 2048, 256
 X = torch.from_numpy(syn.stimuli(N, d)).cuda(); r = torch.from_numpy(syn.cell_inputs(N, 0)[0]).cuda()

@@ -1,7 +1,7 @@
 """Timing of the truncated-rank closure: fused entry vs step-by-step formulation (N=4096, d=256)."""
 import os, sys, time, warnings
 import numpy as np, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from gaussian_processes_amd import utils as gp, synthetic as syn
 KEYS = syn.THETA_KEYS; LOWER, UPPER = syn.limits()
 def tth(v): return {k: torch.tensor(float(x), dtype=torch.float64, requires_grad=True) for k, x in zip(KEYS, v)}

@@ -1,7 +1,7 @@
 """Micro-benchmark of the big triangular GEMM shapes of one fit (N=8192) with walk/tile variants."""
 import os, sys
 import torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from gaussian_processes_amd import _lib
 lib = _lib.load()
 dev = torch.device("cuda:0")

@@ -3,7 +3,7 @@ condition number of the matrix: factor residual, inverse residual and log-determ
 M = Q diag(lambda) Q^T with log-spaced eigenvalues, beside LAPACK's potrf (numpy) on the same matrices."""
 import os, sys
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from gaussian_processes_amd import utils as gp
 

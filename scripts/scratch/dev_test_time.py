@@ -1,5 +1,5 @@
 import os, sys, time, io, contextlib, warnings
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from gaussian_processes_amd import utils as gp, synthetic as syn
 N, d, n_px = 8192, 256, 16

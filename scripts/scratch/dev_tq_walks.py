@@ -1,6 +1,6 @@
 """T = L^-1 L_V and Q = I - T T^T shapes: stream-K tile-walk variants (dev)."""
 import os, sys, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from gaussian_processes_amd import _lib
 lib = _lib.load(); dev = torch.device("cuda:0")
 n = 8192

@@ -1,6 +1,6 @@
 import contextlib, io, os, sys, warnings
 import numpy as np, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from gaussian_processes_amd import utils as gp, synthetic as syn, _lib
 g = np.load("tests/golden/g6_vargp_full_N128.npz")
 KEYS = syn.THETA_KEYS; LOWER, UPPER = syn.limits()

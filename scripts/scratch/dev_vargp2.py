@@ -1,7 +1,7 @@
 import contextlib, io, os, sys, warnings
 import numpy as np, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tests"))
 from gaussian_processes_amd import utils as gp
 import test_gpu_dropin as t
 g = np.load("tests/golden/g6_vargp_full_N128.npz")

@@ -1,6 +1,6 @@
 """XCD-aware schedule (walk bit 3) against the current walks on the fit's large launch shapes."""
 import os, sys, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from gaussian_processes_amd import _lib
 lib = _lib.load(); dev = torch.device("cuda:0")
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
