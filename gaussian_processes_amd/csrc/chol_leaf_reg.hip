@@ -335,6 +335,11 @@ __global__ __launch_bounds__(RL_THREADS, 2) void chol_leaf_reg_kernel(LeafBatchT
   __shared__ __attribute__((aligned(16))) R Dbuf[2][16 * RPS];   // inverse of the 16 x 16 diagonal factor of panel j
   __shared__ __attribute__((aligned(16))) R Dgb[2][16 * RPS];    // mailbox: diagonal tile S[j, j], final through panel j - 2
   __shared__ __attribute__((aligned(16))) R Sx[16 * RPS];        // scratch of the pivot wave (layout changes)
+  // Arrival counter of the barrier B2 (between the row solve (2) and the update pass (3) of a panel).  B2 is a
+  // barrier of the four tile waves only: the pivot wave never reads what (2) writes, and made to wait for it (an
+  // s_barrier is workgroup-wide) it idled 1 k cycles per panel at the head of the kernel's critical chain.  It still
+  // ARRIVES, once its reads of the raw column are done -- the update pass overwrites that buffer -- but does not wait.
+  __shared__ unsigned b2_arrivals;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int fr = lane & 15;
@@ -342,6 +347,15 @@ __global__ __launch_bounds__(RL_THREADS, 2) void chol_leaf_reg_kernel(LeafBatchT
 #pragma unroll
   for (int r = 0; r < 4; ++r) kr[r] = Real<R>::crow(lane, r);
 
+  if (tid == 0) b2_arrivals = 0u;          // (visible to everybody behind B0)
+  auto b2_arrive = [&]() {                 // everything this wave has sent to LDS so far is done, then one count
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (lane == 0) __hip_atomic_fetch_add(&b2_arrivals, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  };
+  auto b2_wait = [&](unsigned target) {    // tile waves: until all five waves have arrived `target / 5` times
+    while (__hip_atomic_load(&b2_arrivals, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target) { }
+    asm volatile("" ::: "memory");
+  };
   if (wave == 4) {
     // ================= the pivot wave: the pivot chains, one panel ahead of the tile waves =================
     // the chains are the critical path of the kernel and VALU-issue bound; the wave shares its SIMD with a
@@ -412,28 +426,26 @@ __global__ __launch_bounds__(RL_THREADS, 2) void chol_leaf_reg_kernel(LeafBatchT
       lds_barrier();   // B1(kb)
       LEAF_STAMP(kb, 4);
       if (nx < 8) {
-        // L[nx, kb] = S[nx, kb] Dinv^T  (the same product the tile waves form in (2): same bits)
+        // L[nx, kb]^T = Dinv S[nx, kb]^T: the products and the order of the sums of L[nx, kb] = S[nx, kb] Dinv^T, which
+        // the tile waves form in (2) (same bits), with the operands exchanged -- the C/D registers then hold
+        // L^T[k, n] = L[n, k], which is the A fragment L[m, k] AND the B fragment L^T[k, n] of the next product
+        // as they stand: no trip through LDS between the two
         Acc lt = acc_zero<R>();
 #pragma unroll
-        for (int r = 0; r < 4; ++r) lt = Real<R>::mfma(Raw[(16 * nx + fr) * RPS + kr[r]], Dv[fr * RPS + kr[r]], lt);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) Sx[kr[r] * RPS + fr] = lt[r];
-        lds_fence();
+        for (int r = 0; r < 4; ++r) lt = Real<R>::mfma(Dv[fr * RPS + kr[r]], Raw[(16 * nx + fr) * RPS + kr[r]], lt);
         // S[nx, nx] -= L[nx, kb] L[nx, kb]^T  on the mailbox copy (final through panel kb - 1)
         Acc sd;
-        R f[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          f[r] = Sx[fr * RPS + kr[r]];
-          sd[r] = Dgb[nx & 1][kr[r] * RPS + fr];
-        }
+        for (int r = 0; r < 4; ++r) sd[r] = Dgb[nx & 1][kr[r] * RPS + fr];
+        b2_arrive();   // B2(kb): the raw column has been read (the MFMAs above consumed it); no wait
 #pragma unroll
-        for (int r = 0; r < 4; ++r) sd = Real<R>::mfma(-f[r], f[r], sd);
+        for (int r = 0; r < 4; ++r) sd = Real<R>::mfma(-lt[r], lt[r], sd);
 #pragma unroll
         for (int r = 0; r < 4; ++r) Sx[kr[r] * RPS + fr] = sd[r];     // row-major for the row-per-lane pivot sweep
         lds_fence();
+      } else {
+        b2_arrive();
       }
-      lds_barrier();   // B2(kb)
       LEAF_STAMP(kb, 5);
       if (nx < 8) {
         LEAF_STAMP(nx, 0);
@@ -520,7 +532,8 @@ __global__ __launch_bounds__(RL_THREADS, 2) void chol_leaf_reg_kernel(LeafBatchT
         }
       }
     }
-    lds_barrier();   // B2(kb): L[., kb] is in LDS
+    b2_arrive();
+    b2_wait(5u * (unsigned)(kb + 1));   // B2(kb): L[., kb] is in LDS, and the pivot wave is done with the raw column
     // ---- (3) every tile wave updates its tiles from panel kb (leaf_update_pass, one specialisation per wave)
     switch (wave) {
       case 0: leaf_update_pass<R, 0>(acc, xrow, P, Dv, RawN, Dgb[0], Dgb[1], kb, kr, fr); break;
