@@ -1,17 +1,15 @@
 // Cholesky leaf, register-resident variant: factor one 128 x 128 diagonal block and invert the
-// factor with the matrix held in the accumulator registers of four waves and only the current
-// 16-column panel in LDS (21 KiB instead of the 133 KiB of chol_leaf.hip).
+// factor with the matrix held in the accumulator registers of four tile waves and only the current
+// 16-column panel in LDS (48 KiB instead of the 133 KiB of chol_leaf.hip); a fifth wave runs the pivot
+// chains one panel ahead.
 //
-// Why: the leaf sits on the critical path of both factorisation chains 2N/128 times per fit, and
-// the two chains run concurrently on two streams.  A leaf that needs 133 KiB of LDS can only start
-// on a CU with no other workgroup, so while the other chain (or a look-ahead GEMM of the same
-// chain) keeps every CU busy with two 64 KiB GEMM workgroups the leaf waits for a whole CU to
-// drain.  With <= 32 KiB of LDS and <= 128 VGPRs this kernel fits beside two such workgroups on
-// any CU (2 x 64 + 32 = 160 KiB; 2 x 192 + 128 = 512 VGPRs per SIMD lane) and starts at once.
+// Why: the leaf sits on the critical path of both factorisation chains 2N/128 times per fit (64 launches of
+// two workgroups at the headline; a third of a unit's time at N = 2048).
 //
 // Layout.  The block is cut into 8 x 8 tiles of 16 x 16; tile (i, j), i >= j, lives in the MFMA
-// C/D layout (4 values per lane) in the registers of the wave that owns tile COLUMN j: wave w owns
-// columns w and 7 - w (9 tiles each).  Column ownership is what makes the in-place inverse
+// C/D layout (4 values per lane) in the registers of the wave that owns tile COLUMN j (rl_col_a / rl_col_b
+// below: wave 0, which shares its SIMD with the pivot wave, owns columns 6 and 7 = 3 tiles, the others two
+// columns of 11 tiles each).  Column ownership is what makes the in-place inverse
 // possible: for the fp64 16x16x4 MFMA the C/D register r of a tile holds exactly the rows
 // k_r(lane) = (lane >> 4) + 4 r that the B operand of sub-step r needs (fp32: 4 (lane >> 4) + r, the
 // sum over k simply runs in that order), so a register tile X[k, j] is used directly as the B
@@ -19,19 +17,24 @@
 // both, i.e. as long as tiles of one column stay together.
 //
 // Right-looking over the eight 16-column panels kb:
-//   (1) the owner of column kb writes its tiles S[kb.., kb] (the Schur complement so far) to the
-//       LDS panel P[128][16] and factors the 16 x 16 diagonal block with a row per lane, pivots
-//       and multipliers moving between lanes with v_readlane; it also inverts that factor
-//       (Dinv, a column per lane) -- the panel solve below is then an MFMA product;
-//   (2) the rows below the diagonal block:  L[i, kb] = S[i, kb] Dinv^T,  one tile per wave and
-//       pass, written back to P and to global memory;
-//   (3) every wave updates its own tiles from the panel:
+//   (1) pivot wave: the 16 x 16 diagonal block of panel kb with a row per lane, pivots and multipliers moving
+//       between lanes by DPP row broadcasts fused into the FMAs; the same sweep inverts the factor (Dinv), so the
+//       panel solve below is an MFMA product.  The wave works one panel ahead: behind barrier B1(kb) it forms
+//       its own copy of L[kb + 1, kb], applies the last Schur update to the diagonal tile of column kb + 1 (handed
+//       over through an LDS mailbox) and runs the chain of panel kb + 1 beside the tile waves' update pass;
+//   (2) tile waves: the rows below the diagonal block,  L[i, kb] = S[i, kb] Dinv^T,  two tiles per wave,
+//       written to the LDS panel P and to global memory; barrier B2 (tile waves only, see b2_arrivals);
+//   (3) every tile wave updates its own tiles from the panel (leaf_update_pass, specialised per wave):
 //         columns j > kb (still Schur complement):  S[i, j] -= L[i, kb] L[j, kb]^T
 //         columns j <= kb (already inverse):        X[kb, j] = -Dinv Y[kb, j]   (X[kb, kb] = Dinv)
 //                                                   Y[i, j] += L[i, kb] X[kb, j]   for i > kb
 //       so the registers of column j hold S[., j] until panel j has been factored and the rows of
 //       L^-1 (finished rows X, running sums Y) afterwards: the inverse costs no extra storage and
 //       is complete when the last panel is.
+// Rounds: 48.7 us (LDS-resident, r01) -> 45 (registers, r02) -> 36.6 (pivot wave, r03) -> 28.8 us (r04: update pass
+// specialised per wave with its operands requested ahead, 3 / 11 / 11 / 11 tiles, the first chain under the tile
+// waves' prologue, B2 without the pivot wave); per panel now 1.6 k cycles before the chain, 4.4 k chain, 1.5 k
+// write-back on the pivot wave against 2.3 k solve + 5.4 k update pass on the tile waves.
 // info: LAPACK-style, as chol_leaf.hip (first non-positive pivot, offending pivot replaced by 1).
 #include "gemm_core.h"
 #include "kernels.h"
@@ -196,80 +199,106 @@ __host__ __device__ constexpr int rl_nslots(int w) { return (8 - rl_col_a(w)) + 
 __host__ __device__ constexpr int rl_slot_i(int w, int t) { return t < 8 - rl_col_a(w) ? rl_col_a(w) + t : rl_col_b(w) + (t - (8 - rl_col_a(w))); }
 __host__ __device__ constexpr int rl_slot_j(int w, int t) { return t < 8 - rl_col_a(w) ? rl_col_a(w) : rl_col_b(w); }
 
-// Step (3) of a panel for tile wave W, specialised per wave: the tile coordinates of the nine slots are compile-time
-// constants (LDS offsets become immediates, the column fragment of a slot is known, every guard compares the panel
-// counter with a constant), while the panel loop around it stays rolled -- four copies of this pass instead of one
-// generic copy whose guards and addresses are re-derived from the wave index for every slot and panel (measured on the
-// generic copy: 3.8 k cycles per panel with only two active slots, 5.5-7.5 k with all of them, for at most 2.3 k cycles
-// of matrix-pipe issue).  All LDS operands are requested up front and waited for once.
-template <typename R, int W>
-__device__ __forceinline__ void leaf_update_pass(typename Real<R>::acc_t (&acc)[RL_SLOTS], typename Real<R>::acc_t& xrow,
-                                                 const R* __restrict__ P, const R* __restrict__ Dv, R* __restrict__ RawN,
-                                                 R* __restrict__ Dg0, R* __restrict__ Dg1, int kb, const int (&kr)[4], int fr) {
+// One tile column C of wave W in panel kb (slots T0 .. T0 + 7 - C hold rows C .. 7).  Either the whole column is
+// still Schur complement (C > kb) or it is in its inverse phase (row kb becomes X, the rows below running sums):
+// ONE wave-uniform branch per column and pass, the slots inside straight-line apart from the one special tile; every
+// product accumulates in place.
+template <typename R, int W, int C, int T0>
+__device__ __forceinline__ void leaf_update_column(typename Real<R>::acc_t (&acc)[RL_SLOTS], const R* __restrict__ P,
+                                                   const R (&dneg)[4], const typename Real<R>::acc_t& dvt, R* __restrict__ RawN,
+                                                   R* __restrict__ Dg0, R* __restrict__ Dg1, int kb, const int (&kr)[4], int fr) {
   using Acc = typename Real<R>::acc_t;
-  constexpr int NSL = rl_nslots(W), CA = rl_col_a(W), CB = rl_col_b(W);
+  constexpr int NR = 8 - C;          // rows C .. 7
   const int nx = kb + 1;
-  // the row fragment L[i, kb] of slot t + 1 is requested before the products of slot t (two fragments in flight); the
-  // column fragments and Dinv, shared by all slots, once at the top
-  R fa[2][4], fbA[4], fbB[4], dd[4];
-  Acc dvt;
-  auto row_frag = [&](int t, R (&f)[4]) {
-    const int i = rl_slot_i(W, t);
+  R fa[2][4];
+  auto row_frag = [&](int i, R (&f)[4]) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) f[r] = P[(16 * i + fr) * RPS + kr[r]];          // rows <= kb: stale, never used
   };
+  if (C > kb) {
+    // Schur complement  S[i, C] -= L[i, kb] L[C, kb]^T: the column fragment negated once
+    R nfb[4];
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    fbA[r] = P[(16 * CA + fr) * RPS + kr[r]];
-    fbB[r] = P[(16 * CB + fr) * RPS + kr[r]];
-    dd[r] = Dv[fr * RPS + kr[r]];
-    dvt[r] = Dv[kr[r] * RPS + fr];
-  }
-  row_frag(0, fa[0]);
+    for (int r = 0; r < 4; ++r) nfb[r] = -P[(16 * C + fr) * RPS + kr[r]];
+    row_frag(C, fa[0]);
 #pragma unroll
-  for (int t = 0; t < NSL; ++t) {
-    const int i = rl_slot_i(W, t), j = rl_slot_j(W, t);
-    Acc& a = acc[t];
-    if (t + 1 < NSL) row_frag(t + 1, fa[(t + 1) & 1]);
-    const R (&f)[4] = fa[t & 1];
-    if (j > kb) {
-      if (i == nx && j == nx) continue;   // the pivot wave took this tile over (mailbox of the previous panel)
-      // Schur complement  S[i, j] -= L[i, kb] L[j, kb]^T
+    for (int t = 0; t < NR; ++t) {
+      const int i = C + t;
+      Acc& a = acc[T0 + t];
+      if (t + 1 < NR) row_frag(i + 1, fa[(t + 1) & 1]);
+      const R (&f)[4] = fa[t & 1];
+      if (!(t == 0 && C == nx)) {           // the diagonal tile of column kb + 1 was taken over by the pivot wave
 #pragma unroll
-      for (int r = 0; r < 4; ++r) a = Real<R>::mfma(-f[r], j == CA ? fbA[r] : fbB[r], a);
-      if (j == nx) {
+        for (int r = 0; r < 4; ++r) a = Real<R>::mfma(f[r], nfb[r], a);
+      }
+      if (C == nx && t > 0) {
         // final through panel kb: a row of the raw column of the next panel
 #pragma unroll
         for (int r = 0; r < 4; ++r) RawN[(16 * i + kr[r]) * RPS + fr] = a[r];
-      } else if (i == nx + 1 && j == nx + 1) {
+      } else if (C == nx + 1 && t == 0) {
         // the diagonal tile of column kb + 2, final through panel kb: into the mailbox of the pivot wave
-        R* Dg = (j & 1) ? Dg1 : Dg0;
+        R* Dg = (C & 1) ? Dg1 : Dg0;
 #pragma unroll
         for (int r = 0; r < 4; ++r) Dg[kr[r] * RPS + fr] = a[r];
       }
-    } else if (i == kb) {
-      // row kb of the inverse:  X[kb, kb] = Dinv,  X[kb, j] = -Dinv Y[kb, j]
-      Acc nxv;
-      if (j == kb) {
-        nxv = dvt;
-      } else {
-        nxv = acc_zero<R>();
-#pragma unroll
-        for (int r = 0; r < 4; ++r) nxv = Real<R>::mfma(-dd[r], a[r], nxv);
-      }
-      a = nxv;
-      xrow = nxv;
-    } else if (i > kb) {
-      // running sums of the rows still to come:  Y[i, j] += L[i, kb] X[kb, j]
-      Acc y = (j == kb) ? acc_zero<R>() : a;  // column kb held the raw panel until now
-#pragma unroll
-      for (int r = 0; r < 4; ++r) y = Real<R>::mfma(f[r], xrow[r], y);
-      a = y;
+      __builtin_amdgcn_sched_barrier(0);    // (see leaf_update_pass)
     }
-    // nothing moves across a slot boundary: left to itself the scheduler hoists the row-fragment reads of ALL slots to
-    // the top of the pass (88 more registers live at once: spills)
-    __builtin_amdgcn_sched_barrier(0);
+  } else {
+    // inverse phase: X[kb, C] = -Dinv Y[kb, C]  (X[kb, kb] = Dinv), then  Y[i, C] += L[i, kb] X[kb, C]  for i > kb
+    // (the row-kb slot is found by an unrolled search: a run-time register index is not an option)
+    Acc xrow = acc_zero<R>();
+#pragma unroll
+    for (int t = 0; t < NR; ++t) {
+      if (C + t == kb) {
+        if (C == kb) {
+          xrow = dvt;
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) xrow = Real<R>::mfma(dneg[r], acc[T0 + t][r], xrow);
+        }
+        acc[T0 + t] = xrow;
+      }
+    }
+    row_frag(C, fa[0]);
+#pragma unroll
+    for (int t = 0; t < NR; ++t) {
+      const int i = C + t;
+      Acc& a = acc[T0 + t];
+      if (t + 1 < NR) row_frag(i + 1, fa[(t + 1) & 1]);
+      const R (&f)[4] = fa[t & 1];
+      if (i > kb) {
+        if (C == kb) a = acc_zero<R>();     // column kb held the raw panel until now
+#pragma unroll
+        for (int r = 0; r < 4; ++r) a = Real<R>::mfma(f[r], xrow[r], a);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
   }
+}
+
+// Step (3) of a panel for tile wave W, specialised per wave: the tile coordinates of the slots are compile-time
+// constants (LDS offsets become immediates, every guard compares the panel counter with a constant), while the panel
+// loop around it stays rolled -- four copies of this pass instead of one generic copy whose guards and addresses are
+// re-derived from the wave index for every slot and panel (measured on the generic copy: 3.8 k cycles per panel with
+// only two active slots, 5.5-7.5 k with all of them, for at most 2.3 k cycles of matrix-pipe issue).  The row fragment
+// L[i, kb] of the next slot is requested before the products of the current one; nothing moves across a slot boundary
+// (sched_barrier): left to itself the scheduler hoists the fragment reads of ALL slots to the top of the pass (88 more
+// registers live at once: spills).
+template <typename R, int W>
+__device__ __forceinline__ void leaf_update_pass(typename Real<R>::acc_t (&acc)[RL_SLOTS], const R* __restrict__ P,
+                                                 const R* __restrict__ Dv, R* __restrict__ RawN, R* __restrict__ Dg0,
+                                                 R* __restrict__ Dg1, int kb, const int (&kr)[4], int fr) {
+  using Acc = typename Real<R>::acc_t;
+  constexpr int CA = rl_col_a(W), CB = rl_col_b(W);
+  R dneg[4];
+  Acc dvt;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    dneg[r] = -Dv[fr * RPS + kr[r]];
+    dvt[r] = Dv[kr[r] * RPS + fr];
+  }
+  leaf_update_column<R, W, CA, 0>(acc, P, dneg, dvt, RawN, Dg0, Dg1, kb, kr, fr);
+  leaf_update_column<R, W, CB, 8 - CA>(acc, P, dneg, dvt, RawN, Dg0, Dg1, kb, kr, fr);
 }
 
 // Prologue / epilogue of tile wave W (its tiles in, the raw column 0 and the first two diagonal tiles into LDS; the
@@ -478,7 +507,6 @@ __global__ __launch_bounds__(RL_THREADS, 2) void chol_leaf_reg_kernel(LeafBatchT
   //                                                                                              [B1(j + 1)]
   // so the chain  Dinv(j) -> L[j + 1, j] -> S[j + 1, j + 1] -> pivots(j + 1)  never leaves the pivot wave and waits
   // for nobody; two barriers per panel, no flags.
-  Acc xrow = acc_zero<R>();  // X[kb, j] of the column being walked (its row-kb slot comes before its later rows)
 #pragma unroll 1
   for (int kb = 0; kb < 8; ++kb) {
     // Left alone, the compiler hoists every LDS offset and store address of every slot of all four specialised
@@ -536,10 +564,10 @@ __global__ __launch_bounds__(RL_THREADS, 2) void chol_leaf_reg_kernel(LeafBatchT
     b2_wait(5u * (unsigned)(kb + 1));   // B2(kb): L[., kb] is in LDS, and the pivot wave is done with the raw column
     // ---- (3) every tile wave updates its tiles from panel kb (leaf_update_pass, one specialisation per wave)
     switch (wave) {
-      case 0: leaf_update_pass<R, 0>(acc, xrow, P, Dv, RawN, Dgb[0], Dgb[1], kb, kr, fr); break;
-      case 1: leaf_update_pass<R, 1>(acc, xrow, P, Dv, RawN, Dgb[0], Dgb[1], kb, kr, fr); break;
-      case 2: leaf_update_pass<R, 2>(acc, xrow, P, Dv, RawN, Dgb[0], Dgb[1], kb, kr, fr); break;
-      default: leaf_update_pass<R, 3>(acc, xrow, P, Dv, RawN, Dgb[0], Dgb[1], kb, kr, fr); break;
+      case 0: leaf_update_pass<R, 0>(acc, P, Dv, RawN, Dgb[0], Dgb[1], kb, kr, fr); break;
+      case 1: leaf_update_pass<R, 1>(acc, P, Dv, RawN, Dgb[0], Dgb[1], kb, kr, fr); break;
+      case 2: leaf_update_pass<R, 2>(acc, P, Dv, RawN, Dgb[0], Dgb[1], kb, kr, fr); break;
+      default: leaf_update_pass<R, 3>(acc, P, Dv, RawN, Dgb[0], Dgb[1], kb, kr, fr); break;
     }
     if (wave == 0) {
       // wave 0 owns three tiles and is done with its pass 1.5 k cycles before the others: it writes the zeros of the
