@@ -810,7 +810,7 @@ def _stabilised_basis(K_tilde, route=None):
 
 import os as _os_mod
 _FORCE_EIGH = bool(_os_mod.environ.get("GPFIT_FORCE_EIGH"))   # tuning / A-B knob: always take the eigh route
-_EIGTOP_MIN_N = 4096   # below this the full eigh is as fast (N = 3072: 91 ms either way)
+_EIGTOP_MIN_N = 2048   # below this the block (twice the kept count: ~1024 columns) is most of the matrix and the full eigh as fast
 # What the truncated regime's basis B is made of at N >= 4096 (module global read at call time, like EIGVAL_TOL):
 #   "subspace"     (default) the canonical orthonormal basis of the kept EIGENSPACE: no dense eigendecomposition at
 #                  all; K_tilde_b = B^T K~ B is a dense n x n matrix.  Everything downstream is invariant under the
