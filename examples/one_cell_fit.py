@@ -22,6 +22,7 @@ import torch
 ap = argparse.ArgumentParser()
 ap.add_argument("--n", type=int, default=512)
 ap.add_argument("--d", type=int, default=64, help="pixels; a square grid")
+ap.add_argument("--ntilde", type=int, default=None, help="inducing images (the first ntilde of the training set); default: all")
 ap.add_argument("--maxiter", type=int, default=4)
 ap.add_argument("--nestep", type=int, default=2)
 ap.add_argument("--nmstep", type=int, default=6)
@@ -64,10 +65,11 @@ lower, upper = syn.limits()
 
 def fresh_start():
     theta = {k: torch.tensor(float(v), dtype=torch.float64, requires_grad=True) for k, v in syn.theta0().items()}
-    fit_parameters = {"ntilde": args.n, "maxiter": args.maxiter, "nEstep": args.nestep, "nMstep": args.nmstep,
+    ntilde = args.ntilde or args.n
+    fit_parameters = {"ntilde": ntilde, "maxiter": args.maxiter, "nEstep": args.nestep, "nMstep": args.nmstep,
                       "nFparamstep": args.nfstep, "kernfun": "acosker", "cellid": 0, "n_px_side": n_px,
                       "display_hyper": False}
-    return {"fit_parameters": fit_parameters, "xtilde": X, "hyperparams_tuple": (theta, lower, upper),
+    return {"fit_parameters": fit_parameters, "xtilde": X if ntilde == args.n else X[:ntilde].clone(), "hyperparams_tuple": (theta, lower, upper),
             "f_params": {"logA": torch.tensor(syn.F_PARAMS["logA"], dtype=torch.float64, requires_grad=True),
                          "lambda0": torch.tensor(syn.F_PARAMS["lambda0"], dtype=torch.float64)}}
 
@@ -95,7 +97,8 @@ if err_dict["is_error"]:
     raise err_dict["error"]
 lm = fit_model["values_track"]["loss_track"]["logmarginal"]
 print(f"backend: {backend}")
-print(f"N={args.n} d={args.d} EIGVAL_TOL={args.tol:g}: kept {fit_model['B'].shape[1]} of {args.n} eigen-directions")
+print(f"N={args.n} ntilde={args.ntilde or args.n} d={args.d} EIGVAL_TOL={args.tol:g}: kept {fit_model['B'].shape[1]} of {args.ntilde or args.n} eigen-directions"
+      f" (basis route {fit_model.get('basis_route', 'n/a')})")
 print(f"varGP: {t_fit:.2f} s  ({args.maxiter} iterations x [{args.nestep} E, {args.nfstep} f-param, {args.nmstep} M]"
       + (f"; first run in this process {fit_times[0]:.2f} s" if len(fit_times) > 1 else "") + f");  test(): {t_test:.3f} s")
 print("logmarginal per iteration:", " ".join(f"{float(v):.4f}" for v in lm))
