@@ -48,7 +48,11 @@ namespace gpfit {
 #ifdef GPFIT_LEAF_STAMPS
 __device__ long long g_leaf_stamps[9 * 8];
 __device__ long long g_leaf_wave_end[8 * 4];     // end of the update pass (3) per panel and tile wave
+#ifdef GPFIT_LEAF_STAMPS_MIN   // only the arrivals at B1 (the stamps in front of a barrier cost nothing extra) and kernel begin / end
+#define LEAF_STAMP(kb, ph) do { if (((ph) == 3 || (kb) == 8) && (threadIdx.x & 63) == 0) g_leaf_stamps[(kb) * 8 + (ph)] = (long long)__builtin_readcyclecounter(); } while (0)
+#else
 #define LEAF_STAMP(kb, ph) do { if ((threadIdx.x & 63) == 0) g_leaf_stamps[(kb) * 8 + (ph)] = (long long)__builtin_readcyclecounter(); } while (0)
+#endif
 #define LEAF_WAVE_END(kb, w) do { if ((threadIdx.x & 63) == 0) g_leaf_wave_end[(kb) * 4 + (w)] = (long long)__builtin_readcyclecounter(); } while (0)
 #else
 #define LEAF_STAMP(kb, ph) do { } while (0)
@@ -148,15 +152,17 @@ template <int J, bool NOP> __device__ __forceinline__ void dpp_fmac_self(float& 
 }
 
 template <typename R, int K, int J> __device__ __forceinline__ void static_for_cols(R (&v)[16], R vk, R nvk);
-template <typename R, int K, int J> __device__ __forceinline__ void static_for_inv(R (&yh)[16], R m);
+template <typename R, int K, int C> __device__ __forceinline__ void static_for_inv(R (&yh)[4], R m);
 
-// Pivot k of the 16 x 16 factorisation (row i of the block in lane i), then the rest; compile-time
-// recursion because the DPP lane select is an immediate.  The inverse of the factor is built by the
-// same sweep: yh_i = e_i - sum_{k<i} l_ik y_k are the rows of L^-1 before their final division
-// by l_ii; at pivot k the lanes below take  yh_i -= (l_ik / l_kk) yh_k  (columns 0..k) straight
-// from lane k by DPP, which fills issue slots the rsqrt chain of the next pivot leaves empty.
+// Pivot k of the 16 x 16 factorisation, then the rest; compile-time recursion because the DPP lane select is an
+// immediate.  Lane 16 g + i holds row i of the block in v[0..15] -- all four DPP rows (g = 0..3) run the factor sweep
+// redundantly: the lanes would idle otherwise and nothing has to cross a row of 16 lanes -- and columns
+// {g, 4 + g, 8 + g, 12 + g} of row i of the inverse sweep in yh[0..3]: yh_i = e_i - sum_{k<i} l_ik y_k are the rows of
+// L^-1 before their final division by l_ii; at pivot k the lanes below take  yh_i -= (l_ik / l_kk) yh_k  straight
+// from lane k of their own DPP row (the broadcast index is the pivot row: the same for every column, whichever group
+// holds it), columns 0 .. k only: floor(k / 4) + 1 instructions instead of k + 1 (40 instead of 136 per panel).
 template <typename R, int K>
-__device__ __forceinline__ void static_for_pivots(R (&v)[16], R (&yh)[16], R& myr, int& first_bad, int lane, int base) {
+__device__ __forceinline__ void static_for_pivots(R (&v)[16], R (&yh)[4], R& myr, int& first_bad, int lane, int base) {
   if constexpr (K < 16) {
     R p = dpp_bcast_nop<K>(v[K]);
     const bool bad = !(p > (R)0);
@@ -180,11 +186,11 @@ __device__ __forceinline__ void static_for_cols(R (&v)[16], R vk, R nvk) {
     static_for_cols<R, K, J + 1>(v, vk, nvk);
   }
 }
-template <typename R, int K, int J>
-__device__ __forceinline__ void static_for_inv(R (&yh)[16], R m) {
-  if constexpr (J <= K) {
-    dpp_fmac_self<K, J == 0>(yh[J], m);      // yh_i[j] += m_i * (lane k's yh[j])
-    static_for_inv<R, K, J + 1>(yh, m);
+template <typename R, int K, int C>
+__device__ __forceinline__ void static_for_inv(R (&yh)[4], R m) {
+  if constexpr (4 * C <= K) {
+    dpp_fmac_self<K, C == 0>(yh[C], m);      // yh_i[4 C + g] += m_i * (lane k's yh[C]);  columns beyond k hold zeros there
+    static_for_inv<R, K, C + 1>(yh, m);
   }
 }
 
@@ -394,38 +400,43 @@ __global__ __launch_bounds__(RL_THREADS, 2) void chol_leaf_reg_kernel(LeafBatchT
     // factor the 16 x 16 block held row-major in Sx (a row per lane) and invert the factor by the same sweep;
     // Dinv -> Dbuf[nx & 1], the rows of L -> memory
     auto pivot_block = [&](int nx, int lane_o) {
-      R v[16], yh[16];
+      const int li = lane_o & 15, lg = lane_o >> 4;     // row of the block / DPP row (column group of the inverse)
+      R v[16], yh[4];
       {
-        const R* row = Sx + (lane & 15) * RPS;
+        const R* row = Sx + li * RPS;
 #pragma unroll
         for (int q = 0; q < 16 / EPC; ++q) {
           const V w = *reinterpret_cast<const V*>(row + EPC * q);
 #pragma unroll
-          for (int e = 0; e < EPC; ++e) v[EPC * q + e] = (lane < 16) ? w[e] : (R)0;
+          for (int e = 0; e < EPC; ++e) v[EPC * q + e] = w[e];
         }
       }
 #pragma unroll
-      for (int j = 0; j < 16; ++j) yh[j] = (j == lane_o) ? (R)1 : (R)0;
+      for (int c = 0; c < 4; ++c) yh[c] = (4 * c + lg == li) ? (R)1 : (R)0;
       int first_bad = 0;
-      R myr = (R)0;  // lane k keeps 1 / L_kk
+      R myr = (R)0;  // the lanes of row k keep 1 / L_kk
       LEAF_STAMP(nx, 1);
-      static_for_pivots<R, 0>(v, yh, myr, first_bad, lane, 16 * nx);
+      static_for_pivots<R, 0>(v, yh, myr, first_bad, li, 16 * nx);
       LEAF_STAMP(nx, 2);
       if (lane == 0 && first_bad != 0) atomicCAS(info, 0, info_base + first_bad);
+      {
+        // Dinv: every lane its four columns (zero above the diagonal by construction); the diagonal rows of L are never
+        // read from LDS -- only their inverse is -- and go to memory only (first DPP row)
+        R* drow = Dbuf[nx & 1] + li * RPS + lg;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) drow[4 * c] = yh[c] * myr;
+      }
       if (lane < 16) {
-        R* drow = Dbuf[nx & 1] + lane * RPS;
         R* grow = L + (int64_t)(16 * nx + lane) * ldl + 16 * nx;
 #pragma unroll
         for (int q = 0; q < 16 / EPC; ++q) {
-          V lv, dv;
+          V lv;
 #pragma unroll
           for (int e = 0; e < EPC; ++e) {
             const int j = EPC * q + e;
             lv[e] = (j <= lane) ? v[j] : (R)0;
-            dv[e] = yh[j] * myr;                       // zero above the diagonal by construction
           }
-          *reinterpret_cast<V*>(drow + EPC * q) = dv;      // (the diagonal rows of L are never read from LDS --
-          *reinterpret_cast<V*>(grow + EPC * q) = lv;      //  only their inverse is -- and go to memory only)
+          *reinterpret_cast<V*>(grow + EPC * q) = lv;
         }
       }
       LEAF_STAMP(nx, 3);

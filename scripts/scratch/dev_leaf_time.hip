@@ -4,6 +4,9 @@
 #ifndef NO_STAMPS
 #define GPFIT_LEAF_STAMPS 1
 #endif
+#ifdef MIN_STAMPS   // arrivals at B1 only: which side (pivot wave / tile waves) the other waits for
+#define GPFIT_LEAF_STAMPS_MIN 1
+#endif
 #include "../../gaussian_processes_amd/csrc/chol_leaf_reg.hip"
 #include <vector>
 #include <cstdio>
@@ -52,6 +55,13 @@ int main() {
   }
   long long we[32];
   hipMemcpyFromSymbol(we, HIP_SYMBOL(gpfit::g_leaf_wave_end), sizeof(we));
+#ifdef MIN_STAMPS
+  for (int kb = 0; kb < 8; ++kb)
+    printf("panel %d: arrivals at B1(%d): pivot wave %.0f (its chain of panel %d written), tile waves %.0f %.0f %.0f %.0f (update pass of panel %d done)\n", kb, kb + 1,
+           kb + 1 < 8 ? (double)st[(kb + 1) * 8 + 3] - t0 : 0.0, kb + 1, (double)we[kb * 4] - t0, (double)we[kb * 4 + 1] - t0, (double)we[kb * 4 + 2] - t0,
+           (double)we[kb * 4 + 3] - t0, kb);
+  return 0;
+#endif
   for (int kb = 0; kb < 8; ++kb)
     printf("panel %d: update pass of tile waves 0..3 ends %.0f %.0f %.0f %.0f after B2 (%.0f)\n", kb, (double)we[kb * 4] - (double)st[kb * 8 + 5],
            (double)we[kb * 4 + 1] - (double)st[kb * 8 + 5], (double)we[kb * 4 + 2] - (double)st[kb * 8 + 5], (double)we[kb * 4 + 3] - (double)st[kb * 8 + 5],
