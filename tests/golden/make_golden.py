@@ -545,6 +545,11 @@ if __name__ == "__main__":
         # BASELINE configs[0] (one_cell_fit.ipynb:384,390 at N = 512, d = 64) at the reference's default tolerance
         g6(1e-4, "g6_vargp_config0_N512.npz", N=512, nEstep=5, nMstep=5, nFparamstep=3, lean=True)
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "g6big":
+        # a whole default-tolerance EM fit of the real reference at the size where the GPU side builds its basis without
+        # any dense eigendecomposition (N = 4096; d = 64 keeps the reference's CPU time to minutes)
+        g6(1e-4, "g6_vargp_trunc_N4096.npz", N=4096, nEstep=2, nMstep=3, nFparamstep=3, lean=True)
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "g6s":
         g6(1e-4, "g6_vargp_sparse_N128_nt64.npz", ntilde=64)
         sys.exit(0)
@@ -563,3 +568,4 @@ if __name__ == "__main__":
     g10()
     g3_config_size()
     g6(1e-4, "g6_vargp_config0_N512.npz", N=512, nEstep=5, nMstep=5, nFparamstep=3, lean=True)
+    g6(1e-4, "g6_vargp_trunc_N4096.npz", N=4096, nEstep=2, nMstep=3, nFparamstep=3, lean=True)

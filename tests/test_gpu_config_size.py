@@ -287,3 +287,53 @@ def test_fused_closures_on_tight_contexts_with_most_directions_kept(gp, nt, ntil
     a, b = np.array([g_f[k] for k in KEYS]), np.array([g_s[k] for k in KEYS])
     assert abs(l_f - l_s) <= 1e-10 * abs(l_s), (l_f, l_s)
     assert np.abs(a - b).max() <= 1e-8 * np.abs(b).max(), (a, b)
+
+
+def test_vargp_default_tolerance_N4096_matches_reference(gp):
+    """A whole EM fit of the REAL reference at N = 4096 (d = 64, default EIGVAL_TOL: every iteration truncates) against
+    the drop-in `varGP` -> `test`, whose basis at this size comes from the subspace solver without any dense
+    eigendecomposition (`basis_route == 'subspace'`: the columns of B are not the reference's eigenvectors, so the posterior
+    is compared in the ORIGINAL basis): kept count per tracked iteration equal, log-marginal / log-likelihood / KL tracks,
+    final theta and logA, the posterior mean, the diagonal of its covariance and the covariance applied to a probe vector,
+    and both predictions (`at_iteration=None` and `=2`, the latter through a rebuilt basis)."""
+    g = load_golden("g6_vargp_trunc_N4096.npz")
+    N, d = int(g["N"]), int(g["d"])
+    X = T(syn.stimuli(N, d, seed=0))
+    r = T(syn.cell_inputs(N)[0])
+    fit_parameters = {"ntilde": N, "maxiter": int(g["maxiter"]), "nEstep": int(g["nEstep"]), "nMstep": int(g["nMstep"]),
+                      "nFparamstep": int(g["nFparamstep"]), "kernfun": "acosker", "cellid": 0, "n_px_side": 8,
+                      "display_hyper": False}
+    args = {"fit_parameters": fit_parameters, "xtilde": X.clone(), "hyperparams_tuple": (tth(g["theta0"]), LOWER, UPPER),
+            "f_params": fparams()}
+    assert gp.EIGVAL_TOL == float(g["tol"]) == 1e-4
+    Rt = T(np.random.default_rng(5).poisson(0.7, (4, 6, 1)).astype(np.float64))
+    with contextlib.redirect_stdout(io.StringIO()), warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        fit, err = gp.varGP(X, r, **args)
+        _, R_pred, _, _ = gp.test(T(g["Xstar"]), Rt, X_train=X, at_iteration=None, **fit)
+        _, R_pred2, _, _ = gp.test(T(g["Xstar"]), Rt, X_train=X, at_iteration=2, **fit)
+    assert not err["is_error"], err
+    vt = fit["values_track"]
+    kept = [int(v.shape[0]) for v in vt["variation_par_track"]["V_b"]]
+    assert kept == [int(k) for k in g["n_kept_track"]], (kept, g["n_kept_track"])
+    assert set(vt["variation_par_track"]["basis_route"]) == {"subspace"} and fit["basis_route"] == "subspace"
+    d_track = relerr(vt["loss_track"]["logmarginal"].numpy(), g["logmarginal"])
+    d_ll = relerr(vt["loss_track"]["loglikelihood"].numpy(), g["loglikelihood"])
+    d_kl = relerr(vt["loss_track"]["KL"].numpy(), g["KL"])
+    th_final = np.array([float(fit["hyperparams_tuple"][0][k]) for k in KEYS])
+    d_theta = float(np.abs(th_final - g["theta_final"]).max())
+    d_logA = abs(float(fit["f_params"]["logA"]) - float(g["logA_final"]))
+    B = fit["B"]
+    m_orig = gp.matmul(B, fit["m_b"])
+    V_orig = gp.matmul(gp.matmul(B, fit["V_b"]), B, transB=True)
+    probe = T(np.random.default_rng(int(g["probe_seed"])).standard_normal(N))
+    d_m = relerr(m_orig.cpu().numpy(), g["m_orig"])
+    d_vd = relerr(torch.diagonal(V_orig).cpu().numpy(), g["V_orig_diag"])
+    d_vp = relerr(gp.matmul(V_orig, probe).cpu().numpy(), g["V_orig_probe"])
+    d_p, d_p2 = relerr(R_pred.cpu().numpy(), g["R_pred"]), relerr(R_pred2.cpu().numpy(), g["R_pred_it2"])
+    print(f"N=4096 whole fit: kept {kept}, tracks {d_track:.2e} / {d_ll:.2e} / {d_kl:.2e}, theta {d_theta:.2e}, logA {d_logA:.2e}, "
+          f"m {d_m:.2e}, diag V {d_vd:.2e}, V probe {d_vp:.2e}, predictions {d_p:.2e} / {d_p2:.2e}")
+    assert d_track < 1e-5 and d_ll < 1e-5 and d_kl < 1e-4, (d_track, d_ll, d_kl)
+    assert d_theta < 1e-4 and d_logA < 1e-4, (d_theta, d_logA)
+    assert d_m < 1e-4 and d_vd < 1e-4 and d_vp < 1e-4, (d_m, d_vd, d_vp)
+    assert d_p < 1e-4 and d_p2 < 1e-4, (d_p, d_p2)
