@@ -81,7 +81,7 @@ def _hash_matrix(rows, cols, device, dtype):
     return (x.to(dtype) * (1.0 / 2147483648.0) - 1.0).contiguous()
 
 
-def _kept_subspace(Q, Y, S, tol, a_out, matmul, cholesky, angle_tol, max_sign_iterations=40, log=None):
+def _kept_subspace(Q, Y, S, tol, a_out, matmul, cholesky, angle_tol, max_sign_iterations=40, log=None, gemm_into=None):
     """The kept invariant subspace WITHOUT the k x k eigendecomposition (24 ms of rocSOLVER at k = 1024: a third of a
     basis build at N = 8192, more than half at N = 4096), from GEMMs and Cholesky factorisations only.
 
@@ -123,6 +123,7 @@ def _kept_subspace(Q, Y, S, tol, a_out, matmul, cholesky, angle_tol, max_sign_it
     # smallest |x_0| is half the relative distance of the nearest Ritz value from tau -- at least ~13 steps on these
     # spectra -- so the convergence test (a host synchronisation) only starts there.
     its, settled = 0, False
+    inplace = gemm_into is not None and not (k & 15)
     while its < max_sign_iterations:
         X2 = matmul(X, X)
         if its >= 12:
@@ -130,9 +131,19 @@ def _kept_subspace(Q, Y, S, tol, a_out, matmul, cholesky, angle_tol, max_sign_it
             if dev2 < 1e-13 * k:
                 settled = True
                 break
-        X = matmul(X, 1.5 * eye - 0.5 * X2)
-        X = (X + X.T) * 0.5
+        if inplace:
+            # X <- 1.5 X - 0.5 X X^2 as ONE product with beta (no temporaries; powers of a symmetric matrix commute, the
+            # rounding asymmetry of a step is 1e-16: symmetrised every eighth step and at the end)
+            Xn = X.clone()
+            gemm_into(Xn, X, X2, alpha=-0.5, beta=1.5)
+            X = Xn
+            if (its & 7) == 7:
+                X = (X + X.T) * 0.5
+        else:
+            X = matmul(X, 1.5 * eye - 0.5 * X2)
+            X = (X + X.T) * 0.5
         its += 1
+    X = (X + X.T) * 0.5
     if not settled:
         return None
     tr = float(torch.trace(X))
@@ -159,7 +170,7 @@ def _kept_subspace(Q, Y, S, tol, a_out, matmul, cholesky, angle_tol, max_sign_it
     angle = res / (tau - a_out)
     if log is not None:
         log(f"eigtop: subspace route k {k} kept {n} sign iterations {its} residual leaving the block {res:.2e} angle bound {angle:.2e}")
-    return {"B": B.contiguous(), "K_tilde_b": Ktb, "K_tilde_inv_b": Ktib, "n": n, "tau": tau, "lam_max": lam_max,
+    return {"B": B.contiguous(), "U": U, "K_tilde_b": Ktb, "K_tilde_inv_b": Ktib, "n": n, "tau": tau, "lam_max": lam_max,
             "angle": angle, "sign_iterations": its}
 
 
@@ -183,7 +194,7 @@ def _filter_gain(applied, a, tau):
 
 
 def top_eigenpairs(K, tol, matmul, cholesky, k0=None, first_sweeps=None, max_sweeps=60, angle_tol=1e-7, seed=20240229,
-                   log=None, accelerate=True, basis="eigenvectors"):
+                   log=None, accelerate=True, basis="eigenvectors", gemm_into=None, start=None):
     """Eigenpairs of the symmetric positive definite ``K`` with ``lambda > max(lambda_max * tol, tol)``.
 
     Returns ``(eigenvalues ascending [n], eigenvectors [N, n], info)`` or ``None`` when the caller should fall
@@ -197,6 +208,12 @@ def top_eigenpairs(K, tol, matmul, cholesky, k0=None, first_sweeps=None, max_swe
     orthonormal basis of that space.  Falls back to the eigenpair route by itself when the
     eigh-free step declines.
 
+    ``start`` (``basis="subspace"`` only): the ``info["state"]`` of an earlier call on a NEARBY matrix (the same fit, one
+    EM iteration earlier: theta has moved a little) -- its converged block and the coordinates of its kept basis in it.
+    The iteration then starts from that block, measures how far the kept space of the new matrix sticks out of it
+    (the certificate's own quantity, for the old basis) and plans only the sweeps that distance needs: 4-6 instead of
+    9-14 late in a fit.  The stopping criterion is the same; without ``start`` the result is a function of K alone.
+
     ``accelerate`` (round 4): every sweep after the first is shifted, ``Q <- orth((K - s I) Q)``, the shifts running
     through the roots of the Chebyshev polynomial of ``[0, a]``, ``a`` = the smallest Rayleigh quotient of the block
     (an upper bound of everything outside the block; available from the sweep's own product).  The spectrum of these
@@ -205,6 +222,20 @@ def top_eigenpairs(K, tol, matmul, cholesky, k0=None, first_sweeps=None, max_swe
     the shifted ones by 0.08 (9).  The orthonormalisation after EVERY sweep stays: one factor spreads the
     block over lambda_max / tau = 1e4, two would exceed what a Gram matrix in fp64 resolves."""
     import math
+    N_true = K.shape[0]
+    if N_true % 16:
+        # the GEMM wants its inner dimension in multiples of 16: pad K~ ONCE with zero rows / columns (a zero eigenvalue
+        # each, far below any threshold; the rows they add to the basis are exactly zero and are cut off again) instead
+        # of having every product of every sweep pad its operands
+        Np = (N_true + 15) // 16 * 16
+        Kp = torch.zeros((Np, Np), device=K.device, dtype=K.dtype)
+        Kp[:N_true, :N_true] = K
+        out = top_eigenpairs(Kp, tol, matmul, cholesky, k0=k0, first_sweeps=first_sweeps, max_sweeps=max_sweeps, angle_tol=angle_tol,
+                             seed=seed, log=log, accelerate=accelerate, basis=basis, gemm_into=gemm_into, start=start)
+        if out is None:
+            return None
+        vals, vecs, info = out
+        return vals, vecs[:N_true].contiguous(), info
     N = K.shape[0]
     dev, dt = K.device, K.dtype
     gen = torch.Generator(device=dev)
@@ -221,11 +252,19 @@ def top_eigenpairs(K, tol, matmul, cholesky, k0=None, first_sweeps=None, max_swe
     dynamic = accelerate and first_sweeps is None
     if first_sweeps is None:
         first_sweeps = (9 if accelerate else 16) if N >= 4096 else 8
-    Q = torch.randn((N, k), generator=gen, device=dev, dtype=dt)
+    warm = None
+    if (start is not None and basis == "subspace" and dynamic and tuple(start["Q"].shape) == (N, start["Q"].shape[1])
+            and start["Q"].shape[1] <= N // 2 and start["Q"].device == dev):
+        warm = start
+        k = int(start["Q"].shape[1])
+        Q = start["Q"]
+    else:
+        Q = torch.randn((N, k), generator=gen, device=dev, dtype=dt)
     done, sweeps = 0, first_sweeps
-    info = {"products": 0, "grown": 0, "rr": 0}
+    info = {"products": 0, "grown": 0, "rr": 0, "warm": warm is not None}
     a_block = None          # upper bound of the spectrum outside the block, from the last Rayleigh-Ritz step
     a_plan = None           # the same bound as the first (unshifted) sweep of this block gave it
+    warm_res = None         # warm start: ||(I - Q Q^T) K B_old||_F of the old block and kept basis
     while True:
         if k > N // 2:
             return None                      # not a truncation problem any more: a full eigh is the right tool
@@ -234,6 +273,12 @@ def top_eigenpairs(K, tol, matmul, cholesky, k0=None, first_sweeps=None, max_swe
         while i < sweeps:
             Y = matmul(K, Q)
             info["products"] += 1
+            if warm is not None:
+                # first product of a warm start (Q is still the old block): how far K's kept space sticks out of it,
+                # measured on the old kept basis B = Q U:  ||(I - Q Q^T) K B||_F
+                YU = matmul(Y, warm["U"])
+                warm_res = float(torch.linalg.matrix_norm(YU - matmul(Q, matmul(Q, YU, transA=True))))
+                warm = None
             if accelerate and (i > 0 or a_block is not None):
                 if not shifts:
                     if a_block is None:
@@ -249,7 +294,15 @@ def top_eigenpairs(K, tol, matmul, cholesky, k0=None, first_sweeps=None, max_swe
                         if dynamic and a > 0:
                             t = (2.0 * tau_est - a) / a
                             g = t + math.sqrt(max(t * t - 1.0, 0.0))
-                            still = _GAIN_NEEDED * max(1.0, 1e-7 / angle_tol) / _filter_gain(applied, a, tau_est)
+                            need0 = _GAIN_NEEDED
+                            if warm_res is not None:
+                                # the cold start's distance is ~0.5 and needs _GAIN_NEEDED; a smaller one needs that much
+                                # less (never below 30: the block's own bottom directions have to settle too)
+                                angle0 = warm_res / max(tau_est - a, 1e-300)
+                                info["start_angle"] = angle0
+                                need0 = min(_GAIN_NEEDED, max(30.0, _GAIN_NEEDED * 2.0 * angle0))
+                                warm_res = None        # (one plan per call: a grown or re-swept block is planned as before)
+                            still = need0 * max(1.0, 1e-7 / angle_tol) / _filter_gain(applied, a, tau_est)
                             m = math.ceil(math.log(2.0 * max(still, 1.0)) / math.log(g))       # T_m(t) ~ g^m / 2
                             sweeps = i + int(min(max(m, 2), 24))
                     else:
@@ -271,7 +324,7 @@ def top_eigenpairs(K, tol, matmul, cholesky, k0=None, first_sweeps=None, max_swe
         S = matmul(Q, Y, transA=True)
         S = (S + S.T) * 0.5
         if basis == "subspace" and a_plan is not None:
-            sub = _kept_subspace(Q, Y, S, tol, a_plan, matmul, cholesky, angle_tol, log=log)
+            sub = _kept_subspace(Q, Y, S, tol, a_plan, matmul, cholesky, angle_tol, log=log, gemm_into=gemm_into)
             if sub is not None and 4 * sub["n"] > 3 * k and k < N // 2:
                 # nearly every direction of the block is kept: it does not reach below the threshold, grow it
                 grow = min(max(256, (k // 4 + 127) // 128 * 128), N // 2 - k, N - k)
@@ -286,7 +339,8 @@ def top_eigenpairs(K, tol, matmul, cholesky, k0=None, first_sweeps=None, max_swe
             if sub is not None and sub["angle"] <= angle_tol:
                 info.update({"k": k, "sweeps": done, "angle": sub["angle"], "n": sub["n"], "route": "subspace",
                              "sign_iterations": sub["sign_iterations"], "K_tilde_b": sub["K_tilde_b"],
-                             "K_tilde_inv_b": sub["K_tilde_inv_b"], "lam_max": sub["lam_max"]})
+                             "K_tilde_inv_b": sub["K_tilde_inv_b"], "lam_max": sub["lam_max"],
+                             "state": {"Q": Q, "U": sub["U"]}})
                 return None, sub["B"], info
             if sub is not None and done < max_sweeps:
                 # not converged yet: more sweeps on the same block (Chebyshev interval as planned), then again

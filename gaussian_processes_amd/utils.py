@@ -40,9 +40,14 @@ PI32 = 3.1415927410125732            # utils.py:25: float32-rounded pi
 DC_KEYS = ("Amp", "-2log2beta", "-log2rho2", "eps_0x", "eps_0y")
 
 
+_HAVE_GPU = [False]
+
+
 def _device():
-    if not torch.cuda.is_available():
-        raise _lib.GpfitError("gaussian_processes_amd.utils needs an MI355X: there is no CPU fallback")
+    if not _HAVE_GPU[0]:       # (asked once: torch.cuda.is_available() costs 2 us and this is called 30 000 times per fit)
+        if not torch.cuda.is_available():
+            raise _lib.GpfitError("gaussian_processes_amd.utils needs an MI355X: there is no CPU fallback")
+        _HAVE_GPU[0] = True
     return torch.device("cuda", torch.cuda.current_device())
 
 
@@ -226,6 +231,18 @@ def matmul(A, B, transA=False, transB=False, alpha=1.0):
     """``alpha * op(A) @ op(B)`` on the fp64 MFMA GEMM (``gpfit_dgemm``): the torch ``@`` call
     sites of the reference's path.  1-D operands are treated as column/row vectors."""
     lib = _lib.load()
+    # fast path (the subspace solver and the E-steps issue thousands of these per fit: the wrapper's own checks were a
+    # quarter of their cost): 2-D float64 device operands, contiguous, already aligned -- straight to the C ABI
+    if (type(A) is torch.Tensor and type(B) is torch.Tensor and A.dim() == 2 and B.dim() == 2 and A.is_cuda and B.is_cuda
+            and A.dtype is TORCH_DTYPE and B.dtype is TORCH_DTYPE and A.is_contiguous() and B.is_contiguous()):
+        M, K = (A.shape[1], A.shape[0]) if transA else A.shape
+        K2, N = (B.shape[1], B.shape[0]) if transB else B.shape
+        if K == K2 and not (K & 15) and not (M & 1) and not (N & 1) and A.device == B.device:
+            C = torch.empty((M, N), dtype=TORCH_DTYPE, device=A.device)
+            _lib.check(lib.gpfit_dgemm(_stream(), 1 if transA else 0, 0 if transB else 1, M, N, K, float(alpha),
+                                       A.data_ptr(), A.stride(0), B.data_ptr(), B.stride(0), 0.0, C.data_ptr(), N, 0, 0, 0),
+                       "gpfit_dgemm")
+            return C
     A, B = _cu(A), _cu(B)
     va, vb = A.dim() == 1, B.dim() == 1
     if va:
@@ -251,6 +268,20 @@ def matmul(A, B, transA=False, transB=False, alpha=1.0):
     if va:
         return C[0, :].contiguous()
     return C.contiguous()
+
+
+def gemm_into(C, A, B, alpha=1.0, beta=0.0, transA=False, transB=False):
+    """``C <- alpha op(A) op(B) + beta C`` in place (``gpfit_dgemm`` with its beta): 2-D float64 device tensors, contiguous,
+    K a multiple of 16, M and N even.  For iterations that would otherwise allocate and combine (eigtop's sign iteration)."""
+    lib = _lib.load()
+    M, K = (A.shape[1], A.shape[0]) if transA else A.shape
+    K2, N = (B.shape[1], B.shape[0]) if transB else B.shape
+    if K != K2 or tuple(C.shape) != (M, N) or (K & 15) or (M & 1) or (N & 1):
+        raise RuntimeError("gemm_into: shapes do not fit (K % 16, even M and N, C = [M, N])")
+    _lib.check(lib.gpfit_dgemm(_stream(), 1 if transA else 0, 0 if transB else 1, M, N, K, float(alpha), A.data_ptr(),
+                               A.stride(0), B.data_ptr(), B.stride(0), float(beta), C.data_ptr(), C.stride(0), 0, 0, 0),
+               "gpfit_dgemm")
+    return C
 
 
 def cholesky(M, want_inverse=False):
@@ -501,14 +532,22 @@ def Estep(r, KKtilde_inv, m, f_params, f_mean, K_tilde=None, K_tilde_inv=None, V
     if update_V_inv or K_tilde is None or alpha != 1:
         warnings.warn('Estep: only the alpha = 1, update_V_inv = False update on V is implemented')
         raise NotImplementedError
-    r, a, m, f_mean, K_tilde = _cu(r), _cu(KKtilde_inv), _cu(m), _cu(f_mean), _cu(K_tilde)
-    A = math.exp(_scalar(f_params['logA']))
-    g = A * matmul(a, r - f_mean, transA=True)                                    # :1421
-    G = A * A * matmul(a, a * f_mean[:, None], transA=True)                       # :1422
-    n = K_tilde.shape[0]
+    K_tilde = _cu(K_tilde)
     L, _, _, info = cholesky(K_tilde)
     if info != 0:
         raise torch.linalg.LinAlgError(f"Estep: K_tilde is not positive definite (info={info})")
+    return _estep_given_factor(r, KKtilde_inv, m, f_params, f_mean, L)
+
+
+def _estep_given_factor(r, KKtilde_inv, m, f_params, f_mean, L):
+    """The Newton update of ``Estep`` with the Cholesky factor ``L`` of K~ (in the basis in force) supplied: K~ only
+    changes with theta, so ``varGP`` factors it once per EM iteration, not once per E-step (utils.py:1864-1881 runs
+    ``nEstep`` updates between two kernel rebuilds)."""
+    r, a, m, f_mean = _cu(r), _cu(KKtilde_inv), _cu(m), _cu(f_mean)
+    A = math.exp(_scalar(f_params['logA']))
+    g = A * matmul(a, r - f_mean, transA=True)                                    # :1421
+    G = A * A * matmul(a, a * f_mean[:, None], transA=True)                       # :1422
+    n = L.shape[0]
     W = matmul(L, matmul(G, L), transA=True)
     W = (W + W.T) * 0.5 + torch.eye(n, dtype=TORCH_DTYPE, device=W.device)
     _, Lwi, _, info = cholesky(W, want_inverse=True)
@@ -713,7 +752,7 @@ def _all_kept_given_factor(K_tilde, Li):
     return lam_min_lb > max(lam_max_ub * EIGVAL_TOL, EIGVAL_TOL)
 
 
-def _stabilised_basis(K_tilde, route=None):
+def _stabilised_basis(K_tilde, route=None, start=None):
     """Basis the reference works in after its eigen-stabilisation (utils.py:1682-1694): returns
     ``(eigvecs, B, K_tilde_b, K_tilde_inv_b)``.
 
@@ -730,8 +769,14 @@ def _stabilised_basis(K_tilde, route=None):
     ``varGP`` records it with every tracked iteration.  ``route=...`` asks for exactly that route -- what
     ``test(at_iteration=...)`` does with the recorded one, so that a model fitted under one setting
     (``GPFIT_FORCE_EIGH``, another library version) is never evaluated in a different basis: a route that
-    cannot be reproduced raises instead of returning numbers in the wrong coordinates."""
+    cannot be reproduced raises instead of returning numbers in the wrong coordinates.
+
+    ``start``: the solver state a previous call left in ``_BASIS.state`` for a NEARBY kernel matrix (``varGP`` hands the
+    state of one EM iteration to the next: theta has moved a little, the kept eigenspace with it): the subspace solver
+    then starts from that block and plans only the sweeps the measured distance needs.  Same stopping criterion; a call
+    without it is a function of K~ alone (what ``test(at_iteration=...)`` relies on)."""
     n = K_tilde.shape[0]
+    _BASIS.state = None
 
     def truncated_basis(want=None):
         # truncated regime: only the kept eigenspace, by block subspace iteration on the library's GEMM and Cholesky
@@ -743,11 +788,13 @@ def _stabilised_basis(K_tilde, route=None):
             return None
         want = want or ("subspace" if EIGTOP_BASIS == "subspace" else "eigtop")
         top = eigtop.top_eigenpairs(K_tilde, EIGVAL_TOL, matmul, cholesky,
-                                    basis="subspace" if want == "subspace" else "eigenvectors")
+                                    basis="subspace" if want == "subspace" else "eigenvectors", gemm_into=gemm_into,
+                                    start=start if want == "subspace" else None)
         if top is None:
             return None
         vals, vecs, info = top
         if vals is None:
+            _BASIS.state = info.get("state")
             return "subspace", (vecs, vecs, info["K_tilde_b"], info["K_tilde_inv_b"])
         # the first entry stands in for the reference's N x N eigenvector matrix: only the kept columns exist
         return "eigtop", (vecs, vecs, torch.diag(vals), torch.diag_embed(1 / vals))
@@ -1195,10 +1242,14 @@ def varGP(x, r, **kwargs):
     basis_route = [None]   # route of the basis in force (recorded with every tracked iteration)
 
     chol_factor = [None]   # (L, L^-1) of the K~ in force when its basis is the identity, else None
+    estep_factor = [None]  # (K~_b, its Cholesky factor): shared by the E-steps between two kernel rebuilds
+    solver_state = [None]  # the subspace solver's converged block of the previous kernel matrix (warm start)
 
     def project(Kt, K_):
         _BASIS.factor = None
-        eigvecs_, B_, Ktb, Ktib = _stabilised_basis(Kt)
+        eigvecs_, B_, Ktb, Ktib = _stabilised_basis(Kt, start=solver_state[0])
+        solver_state[0] = getattr(_BASIS, "state", None)     # the subspace solver's block, for the next EM iteration
+        _BASIS.state = None
         basis_route[0] = _BASIS.route
         chol_factor[0] = _BASIS.factor if _BASIS.route == "identity" else None
         _BASIS.factor = None
@@ -1336,8 +1387,13 @@ def varGP(x, r, **kwargs):
                             V_b = matmul(B, matmul(V_new, B), transA=True)
                             V_b = (V_b + V_b.T) / 2
                     else:
-                        m_b, V_b = Estep(r=r, KKtilde_inv=KKtilde_inv_b, m=m_b, f_params=f_params, f_mean=f_mean,
-                                         K_tilde=K_tilde_b, K_tilde_inv=K_tilde_inv_b, update_V_inv=False, alpha=1)  # :1880
+                        # :1880, with the factor of K~_b shared by the E-steps of this iteration
+                        if estep_factor[0] is None or estep_factor[0][0] is not K_tilde_b:
+                            L_kb, _, _, info_kb = cholesky(K_tilde_b)
+                            if info_kb != 0:
+                                raise torch.linalg.LinAlgError(f"Estep: K_tilde is not positive definite (info={info_kb})")
+                            estep_factor[0] = (K_tilde_b, L_kb)
+                        m_b, V_b = _estep_given_factor(r, KKtilde_inv_b, m_b, f_params, f_mean, estep_factor[0][1])
                     lambda_m, lambda_var = moments_now()                                        # :1884
                     f_mean = mean_f_given_lambda_moments(f_params, lambda_m, lambda_var)
                     tf = time.time()

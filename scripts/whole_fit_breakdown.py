@@ -1,6 +1,6 @@
 """Where a whole EM fit (varGP through the drop-in module) spends its time, at the reference's default tolerance.
 
-    python scripts/whole_fit_breakdown.py [N] [d] [out.json]
+    python scripts/whole_fit_breakdown.py [N] [d] [out.json] [ntilde] [maxiter,nEstep,nMstep,nFparamstep]
 
 Two runs of the same fit from the same start: one untouched (the wall time that counts), one with every entry
 point of the C ABI and the few torch routines the host side uses (eigh, L-BFGS step) wrapped in synchronised
@@ -22,19 +22,22 @@ from gaussian_processes_amd import _lib, synthetic as syn, utils as gp  # noqa: 
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
 d = int(sys.argv[2]) if len(sys.argv) > 2 else 256
-out_path = sys.argv[3] if len(sys.argv) > 3 else None
+out_path = sys.argv[3] if len(sys.argv) > 3 and sys.argv[3] != "-" else None
+NTILDE = int(sys.argv[4]) if len(sys.argv) > 4 else N          # < N: the sparse regime (the lab's runs: n_t = 3160, ntilde <= 2100)
 n_px = int(round(d ** 0.5))
 dev = torch.device("cuda")
 X = torch.from_numpy(syn.stimuli(N, d)).to(dev)
 r = torch.from_numpy(syn.cell_inputs(N, 0)[0]).to(dev)
 lower, upper = syn.limits()
 SETTINGS = {"maxiter": 4, "nEstep": 2, "nMstep": 6, "nFparamstep": 4}
+if len(sys.argv) > 5:
+    SETTINGS = dict(zip(("maxiter", "nEstep", "nMstep", "nFparamstep"), (int(v) for v in sys.argv[5].split(","))))
 
 
 def start():
     theta = {k: torch.tensor(float(v), dtype=torch.float64, requires_grad=True) for k, v in syn.theta0().items()}
-    fp = dict(SETTINGS, ntilde=N, kernfun="acosker", cellid=0, n_px_side=n_px, display_hyper=False)
-    return {"fit_parameters": fp, "xtilde": X, "hyperparams_tuple": (theta, lower, upper),
+    fp = dict(SETTINGS, ntilde=NTILDE, kernfun="acosker", cellid=0, n_px_side=n_px, display_hyper=False)
+    return {"fit_parameters": fp, "xtilde": X if NTILDE == N else X[:NTILDE].clone(), "hyperparams_tuple": (theta, lower, upper),
             "f_params": {"logA": torch.tensor(syn.F_PARAMS["logA"], dtype=torch.float64, requires_grad=True),
                          "lambda0": torch.tensor(syn.F_PARAMS["lambda0"], dtype=torch.float64)}}
 
@@ -101,7 +104,7 @@ gp._stabilised_basis, gp.eigtop.top_eigenpairs = basis0, eig0
 rows = sorted(((n, c, s) for n, (c, s) in acc.items()), key=lambda t: -t[2])
 accounted = sum(s for _, _, s in rows)
 report = {
-    "what": f"varGP at N={N} d={d}, EIGVAL_TOL={gp.EIGVAL_TOL} (the reference's default), {SETTINGS}, steady state (second fit of the process)",
+    "what": f"varGP at N={N} ntilde={NTILDE} d={d}, EIGVAL_TOL={gp.EIGVAL_TOL} (the reference's default), {SETTINGS}, steady state (second fit of the process)",
     "wall_s": round(wall, 4), "wall_instrumented_s": round(wall_instr, 4),
     "basis_route_per_iteration": list(model["values_track"]["variation_par_track"]["basis_route"]),
     "n_kept": int(model["B"].shape[1]), "logmarginal_track": tracks,
