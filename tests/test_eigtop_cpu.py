@@ -114,3 +114,32 @@ def test_kept_eigenspace_without_a_dense_eigendecomposition():
     Km = (Qm * lam) @ Qm.T
     out = eigtop.top_eigenpairs((Km + Km.T) / 2, 1e-3, cpu_matmul, cpu_cholesky, k0=128, max_sweeps=24, basis="subspace")
     assert out is None or out[2].get("route") != "subspace"
+
+
+def test_warm_start_from_a_nearby_matrix_needs_fewer_sweeps_and_lands_on_the_same_space():
+    """``start=info["state"]`` of a solve on K, handed to the solve of a perturbed K (what varGP does from one EM
+    iteration to the next): fewer sweeps for the same certificate, the same count as eigh and the same space to rounding,
+    the same canonical basis as the cold solve of that matrix to the certificate's accuracy."""
+    n, tol = 900, 1e-4
+    K, lam, Q = kernel_like_matrix(n)
+    K = (K + K.T) / 2
+    cold0 = eigtop.top_eigenpairs(K, tol, cpu_matmul, cpu_cholesky, k0=160, basis="subspace")
+    assert cold0 is not None and cold0[2]["warm"] is False and "state" in cold0[2]
+    g = torch.Generator().manual_seed(9)
+    E = torch.randn(n, n, dtype=torch.float64, generator=g)
+    E = (E + E.T) / 2
+    w = torch.linalg.eigvalsh(K)
+    K2 = K * (1 + 1e-4) + 1e-4 * tol * float(w[-1]) * E / float(torch.linalg.matrix_norm(E, 2))
+    w2, U2 = torch.linalg.eigh(K2)
+    keep2 = w2 > max(float(w2[-1]) * tol, tol)
+    cold = eigtop.top_eigenpairs(K2, tol, cpu_matmul, cpu_cholesky, k0=160, basis="subspace")
+    warm = eigtop.top_eigenpairs(K2, tol, cpu_matmul, cpu_cholesky, k0=160, basis="subspace", start=cold0[2]["state"])
+    assert warm is not None and warm[2]["warm"] is True and warm[2]["route"] == "subspace"
+    assert warm[2]["sweeps"] < cold[2]["sweeps"] and warm[2]["start_angle"] < 1e-2
+    assert warm[2]["angle"] <= 1e-7 and warm[2]["n"] == int(keep2.sum()) == cold[2]["n"]
+    P = U2[:, keep2].T @ warm[1]
+    assert float((P.T @ P - torch.eye(P.shape[1], dtype=torch.float64)).abs().max()) < 1e-9
+    assert float((warm[1] - cold[1]).abs().max()) < 1e-5            # the canonical basis, up to the certificate
+    # a state that does not fit (another size) is ignored: cold solve
+    other = eigtop.top_eigenpairs(K2[:800, :800].contiguous(), tol, cpu_matmul, cpu_cholesky, k0=160, basis="subspace", start=cold0[2]["state"])
+    assert other is None or other[2]["warm"] is False
