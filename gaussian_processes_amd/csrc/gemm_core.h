@@ -243,6 +243,12 @@ template <typename R, bool KMAJOR, int T> struct TileDma {
       __builtin_amdgcn_raw_ptr_buffer_load_lds(
           rs, (__attribute__((address_space(3))) void*)(uintptr_t)(image + (uint32_t)(q0 + i) * 1024u), 16, voff[i], 0, 0, 0);
   }
+  // one of the MI pieces on its own (main loops that spread the pieces of a tile over the sub-steps of a K step)
+  __device__ __forceinline__ void issue_one(uint32_t image, int i) const {
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(base), 0, -1, 0x00020000);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(
+        rs, (__attribute__((address_space(3))) void*)(uintptr_t)(image + (uint32_t)(q0 + i) * 1024u), 16, voff[i], 0, 0, 0);
+  }
   __device__ __forceinline__ void advance() { base += step; }
 };
 
