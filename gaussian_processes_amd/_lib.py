@@ -30,6 +30,8 @@ _SIGS = {
     "gpfit_potrf": (i32, [vp, vp, vp, i64, i64, vp, i64, vp, i64, pd, ctypes.POINTER(i32)]),
     "gpfit_potrf_append": (i32, [vp, vp, vp, i64, vp, i64, i64, vp, pd, ctypes.POINTER(i32)]),
     "gpfit_estep": (i32, [vp, vp, vp, i64, i64, vp, vp, vp, f64, vp, vp, i64]),
+    "gpfit_estep_projected": (i32, [vp, vp, vp, i64, vp, i64, vp, i64, i64, i64, vp, vp, vp, f64, vp, vp, i64, vp, vp,
+                                    vp]),
     "gpfit_fparam_eval": (i32, [vp, vp, vp, vp, vp, i64, f64, i32, f64, vp, pd]),
     "gpfit_set_profile": (i32, [vp, i32]),
     "gpfit_get_profile": (i32, [vp, pd]),

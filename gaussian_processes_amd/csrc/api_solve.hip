@@ -208,6 +208,61 @@ int gpfit_estep(gpfit_ctx* c, void* stream, const double* K, int64_t ldk, int64_
   return 0;
 }
 
+int gpfit_estep_projected(gpfit_ctx* c, void* stream, const double* a, int64_t lda, const double* aL, int64_t ldal,
+                          const double* L, int64_t ldl, int64_t N, int64_t nb, const double* r, const double* m,
+                          const double* f, double logA, double* m_new, double* V_new, int64_t ldv, const double* kv0,
+                          double* lam_m_out, double* lam_var_out) {
+  const bool want_moments = kv0 && lam_m_out && lam_var_out;
+  if (!c || !a || !aL || !L || !r || !m || !f || !m_new || !V_new || N <= 0 || nb <= 0 || lda < nb || ldal < nb ||
+      ldl < nb || ldv < nb || (!want_moments && (kv0 || lam_m_out || lam_var_out))) {
+    set_error("gpfit_estep_projected: bad argument");
+    return -3;
+  }
+  GP_CTX_ENTER(c, "gpfit_estep_projected");
+  hipStream_t s = (hipStream_t)stream;
+  const int n = (int)N, k = (int)nb;
+  const int nrows = (int)round_up(N, TILE), npc = (int)round_up(nb, TILE);
+  if (nrows > c->np_cap || npc > c->np_cap) {
+    set_error("gpfit_estep_projected: problem larger than the context capacity");
+    return -3;
+  }
+  const int64_t ld = npc;
+  const double A = std::exp(logA);
+  double *sv = c->yv, *u = c->bv, *t2 = c->tvec, *z1 = c->mpad, *z = c->rpad, *mo = c->hvec;
+  double *Y = c->Tbuf, *Lp = c->Wbuf, *P = c->Abuf, *V = c->Zbuf, *part = c->TmpV, *aLp = c->LiVbuf, *Zm = c->Cos;
+  GP_HIP(hipMemsetAsync(c->info, 0, 4 * sizeof(int), s));
+  GP_TRY(launch_estep_proj_rows(a, lda, k, m, f, r, n, nrows, A, sv, u, s));
+  GP_TRY(launch_estep_proj_scale(aL, ldal, k, n, nrows, sv, u, Y, want_moments ? aLp : nullptr, ld, npc, part, s));
+  GP_TRY((launch_reduce_slices<double, double>(part, npc, nrows / 32, t2, npc, s)));   // t2 = (a L)^T u
+  // W = I + Y^T Y  (= I + L^T G L, G = A^2 a^T diag(f) a), lower tiles, identity on the padding
+  GP_TRY(gemm_full(s, 1, 1, npc, npc, nrows, 1.0, Y, ld, Y, ld, 0.0, c->Kbuf, ld, 1, 0, 0, 0, c->sk_ws[0]));
+  GP_TRY(launch_add_diag(c->Kbuf, ld, npc, 1.0, s));
+  CholBufs b{c->Kbuf, c->Lbuf, c->Libuf, c->Tmp, ld, c->info, 0, c->sk_ws[0]};
+  GP_TRY(potrf_rec(b, 0, npc, 1, s));
+  // m_new = L W^-1 (a L)^T u
+  GP_TRY(launch_trmv_lower(c->Libuf, ld, npc, t2, z1, s));
+  GP_TRY(launch_trmv_lower_t(c->Libuf, ld, npc, z1, z, c->trmv_part, s));
+  GP_TRY(launch_pack_lower(L, ldl, k, Lp, ld, npc, s));
+  GP_TRY(launch_trmv_lower(Lp, ld, npc, z, mo, s));
+  // V_new = P P^T, P = L L_W^-T  (= (K~^-1 + G)^-1 = solve(I + K~ G, K~), utils.py:1430)
+  GP_TRY(gemm_full(s, 0, 0, npc, npc, npc, 1.0, Lp, ld, c->Libuf, ld, 0.0, P, ld, 0, 1, 2, 0, c->sk_ws[0]));
+  GP_TRY(gemm_full(s, 0, 0, npc, npc, npc, 1.0, P, ld, P, ld, 0.0, V, ld, 1, 0, 0, 0, c->sk_ws[0]));
+  GP_HIP(hipMemcpyAsync(m_new, mo, (size_t)k * sizeof(double), hipMemcpyDeviceToDevice, s));
+  GP_TRY(launch_unpack_sym(V, ld, k, V_new, ldv, s));   // symmetric by construction (utils.py:1438)
+  if (want_moments) {
+    // the moments of lambda the caller evaluates next (utils.py:1090, 1101), from Z = aL L_W^-T: a V_new a^T = Z Z^T
+    GP_TRY(gemm_full(s, 0, 0, nrows, npc, npc, 1.0, aLp, ld, c->Libuf, ld, 0.0, Zm, ld, 0, 0, 2, 0, c->sk_ws[0]));
+    GP_TRY(launch_estep_proj_moments(Zm, ld, k, z1, kv0, n, lam_m_out, lam_var_out, s));
+  }
+  GP_HIP(hipMemcpyAsync(c->info_host, c->info, 4 * sizeof(int), hipMemcpyDeviceToHost, s));
+  GP_HIP(hipStreamSynchronize(s));
+  if (c->info_host[0] != 0) {
+    set_error("gpfit_estep_projected: I + L^T G L is not positive definite (NaN or negative firing rates?)");
+    return c->info_host[0];
+  }
+  return 0;
+}
+
 int gpfit_fparam_eval(gpfit_ctx* c, void* stream, const double* lam_m, const double* lam_var, const double* r,
                       int64_t N, double logA, int closed_form_lambda0, double lambda0_in, double* f_out,
                       double* out_host) {

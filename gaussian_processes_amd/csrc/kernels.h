@@ -169,6 +169,16 @@ int launch_proj_gkb(const double* Bp, int64_t ld, int nb, int n, int np, const d
 int launch_proj_gktb(const double* Ki, const double* P1, const double* P2, int64_t ld, int nb, const double* b, double* G,
                      hipStream_t s);
 int launch_proj_trace(const double* A, int64_t lda, int n, double* out, hipStream_t s);
+// fused E-step in the projected basis (gpfit_estep_projected): per-row scalars s = A sqrt(f), u = A^2 f (a m) + A (r - f)
+// over nrows >= n rows (zero on the padding); then Y = diag(s) aL zero-padded to [nrows][ld] (nrows a multiple of
+// 32) with the slice sums of aL^T u in part[nrows / 32][npc]
+int launch_estep_proj_rows(const double* a, int64_t lda, int nb, const double* mb, const double* f, const double* r,
+                           int n, int nrows, double A, double* sv, double* u, hipStream_t s);
+int launch_estep_proj_scale(const double* aL, int64_t ldal, int nb, int n, int nrows, const double* sv, const double* u,
+                            double* Y, double* aLp /* or nullptr */, int64_t ld, int npc, double* part, hipStream_t s);
+// lam_m = Z z1, lam_var = kv0 + row norms^2 of Z (Z = aL L_W^-T: the moments of lambda behind the update)
+int launch_estep_proj_moments(const double* Z, int64_t ld, int nb, const double* z1, const double* kv0, int n,
+                              double* lam_m, double* lam_var, hipStream_t s);
 
 // ---- E-step / factorisation / firing-rate helpers
 int launch_estep_prep(const double* f, const double* r, const double* m, int n, int np, double A, double* sv,

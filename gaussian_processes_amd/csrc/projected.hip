@@ -149,4 +149,100 @@ int launch_proj_trace(const double* A, int64_t lda, int n, double* out, hipStrea
   return 0;
 }
 
+// ---- fused E-step in the projected basis (gpfit_estep_projected, api_solve.hip)
+// One wave per training point i: lam = a_i . m_b, s_i = A sqrt(f_i), u_i = A^2 f_i lam + A (r_i - f_i)
+// (the right-hand side G m + g of utils.py:1431 before its projection a^T); zero on the padding rows.
+__global__ __launch_bounds__(256) void estep_proj_rows_kernel(const double* __restrict__ a, int64_t lda, int nb,
+                                                               const double* __restrict__ mb, const double* __restrict__ f,
+                                                               const double* __restrict__ r, int n, int nrows, double A,
+                                                               double* __restrict__ sv, double* __restrict__ u) {
+  const int lane = threadIdx.x & 63;
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= nrows) return;
+  double s0 = 0.0;
+  if (i < n) {
+    const double* row = a + (int64_t)i * lda;
+    for (int j = lane; j < nb; j += 64) s0 += row[j] * mb[j];
+  }
+  for (int o = 32; o > 0; o >>= 1) s0 += __shfl_down(s0, o);
+  if (lane == 0) {
+    if (i < n) {
+      const double fi = f[i];
+      sv[i] = A * sqrt(fi);
+      u[i] = A * A * fi * s0 + A * (r[i] - fi);
+    } else {
+      sv[i] = 0.0;
+      u[i] = 0.0;
+    }
+  }
+}
+
+// Y[i][j] = s_i aL[i][j], zero padded to [nrows][ld] (and, if asked for, the zero-padded copy aLp of aL itself);
+// part[slice][j] = sum over the 32 rows of the slice of aL[i][j] u_i (added up slice by slice afterwards: deterministic)
+__global__ __launch_bounds__(256) void estep_proj_scale_kernel(const double* __restrict__ aL, int64_t ldal, int nb, int n,
+                                                                const double* __restrict__ sv, const double* __restrict__ u,
+                                                                double* __restrict__ Y, double* __restrict__ aLp,
+                                                                int64_t ld, int npc, double* __restrict__ part) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= npc) return;
+  const int i0 = blockIdx.y * 32;
+  double acc = 0.0;
+#pragma unroll 8
+  for (int q = 0; q < 32; ++q) {
+    const int i = i0 + q;
+    const double v = (i < n && j < nb) ? aL[(int64_t)i * ldal + j] : 0.0;
+    Y[(int64_t)i * ld + j] = sv[i] * v;
+    if (aLp) aLp[(int64_t)i * ld + j] = v;
+    acc += v * u[i];
+  }
+  part[(int64_t)blockIdx.y * npc + j] = acc;
+}
+
+int launch_estep_proj_rows(const double* a, int64_t lda, int nb, const double* mb, const double* f, const double* r,
+                           int n, int nrows, double A, double* sv, double* u, hipStream_t s) {
+  hipLaunchKernelGGL(estep_proj_rows_kernel, dim3((nrows + 3) / 4), dim3(256), 0, s, a, lda, nb, mb, f, r, n, nrows, A,
+                     sv, u);
+  GP_HIP(hipGetLastError());
+  return 0;
+}
+int launch_estep_proj_scale(const double* aL, int64_t ldal, int nb, int n, int nrows, const double* sv, const double* u,
+                            double* Y, double* aLp, int64_t ld, int npc, double* part, hipStream_t s) {
+  hipLaunchKernelGGL(estep_proj_scale_kernel, dim3((npc + 255) / 256, nrows / 32), dim3(256), 0, s, aL, ldal, nb, n, sv,
+                     u, Y, aLp, ld, npc, part);
+  GP_HIP(hipGetLastError());
+  return 0;
+}
+
+// The moments of lambda behind the update, from Z = aL L_W^-T (one wave per training point):
+//   lam_m_i = a_i . m_new = Z_i . z1 (z1 = L_W^-1 aL^T u),  lam_var_i = kv0_i + a_i V_new a_i^T = kv0_i + |Z_i|^2
+__global__ __launch_bounds__(256) void estep_proj_moments_kernel(const double* __restrict__ Z, int64_t ld, int nb,
+                                                                  const double* __restrict__ z1,
+                                                                  const double* __restrict__ kv0, int n,
+                                                                  double* __restrict__ lam_m, double* __restrict__ lam_var) {
+  const int lane = threadIdx.x & 63;
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= n) return;
+  const double* row = Z + (int64_t)i * ld;
+  double s0 = 0.0, s1 = 0.0;
+  for (int j = lane; j < nb; j += 64) {
+    const double v = row[j];
+    s0 += v * z1[j];
+    s1 += v * v;
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    s0 += __shfl_down(s0, o);
+    s1 += __shfl_down(s1, o);
+  }
+  if (lane == 0) {
+    lam_m[i] = s0;
+    lam_var[i] = kv0[i] + s1;
+  }
+}
+int launch_estep_proj_moments(const double* Z, int64_t ld, int nb, const double* z1, const double* kv0, int n,
+                              double* lam_m, double* lam_var, hipStream_t s) {
+  hipLaunchKernelGGL(estep_proj_moments_kernel, dim3((n + 3) / 4), dim3(256), 0, s, Z, ld, nb, z1, kv0, n, lam_m, lam_var);
+  GP_HIP(hipGetLastError());
+  return 0;
+}
+
 }  // namespace gpfit

@@ -560,6 +560,39 @@ def _estep_given_factor(r, KKtilde_inv, m, f_params, f_mean, L):
     return m_new, V_new
 
 
+def _estep_projected(r, KKtilde_inv, aL, L, m, f_params, f_mean, kv0=None):
+    """``_estep_given_factor`` as ONE device call (``gpfit_estep_projected``: W = I + (diag(A sqrt f) a L)^T (...),
+    its factor and inverse, V = L W^-1 L^T, m = L W^-1 (a L)^T u), with ``aL = a L`` supplied by the caller -- like
+    ``L`` it only changes when the kernel is rebuilt.  A lab-shaped fit (3160 / 2100 images, 30 x 10 E-steps) spends
+    a third of its time in these updates when they are issued product by product.  With ``kv0 = Kvec - rowsum(K o a)``
+    the call also returns the moments of lambda behind the update (what ``lambda_moments`` would compute next)."""
+    r, a, aL, L, m, f_mean = _cu(r), _cu(KKtilde_inv), _cu(aL), _cu(L), _cu(m), _cu(f_mean)
+    a, aL, L = a.contiguous(), aL.contiguous(), L.contiguous()
+    N, nb = a.shape
+    m_new = torch.empty(nb, dtype=TORCH_DTYPE, device=a.device)
+    V_new = torch.empty((nb, nb), dtype=TORCH_DTYPE, device=a.device)
+    eng = get_engine(max(N, nb), 1)
+    lam_m = lam_var = None
+    if kv0 is not None:
+        kv0 = _cu(kv0).contiguous()
+        lam_m = torch.empty(N, dtype=TORCH_DTYPE, device=a.device)
+        lam_var = torch.empty(N, dtype=TORCH_DTYPE, device=a.device)
+    rc = _lib.load().gpfit_estep_projected(eng._ctx, _stream(), a.data_ptr(), a.stride(0), aL.data_ptr(), aL.stride(0),
+                                           L.data_ptr(), L.stride(0), N, nb, r.contiguous().data_ptr(),
+                                           m.contiguous().data_ptr(), f_mean.contiguous().data_ptr(),
+                                           _scalar(f_params['logA']), m_new.data_ptr(), V_new.data_ptr(), V_new.stride(0),
+                                           kv0.data_ptr() if kv0 is not None else None,
+                                           lam_m.data_ptr() if kv0 is not None else None,
+                                           lam_var.data_ptr() if kv0 is not None else None)
+    if rc > 0:
+        raise torch.linalg.LinAlgError(f"Estep: I + L^T G L is not positive definite (info={rc})")
+    if rc != 0:
+        raise _lib.GpfitError(f"gpfit_estep_projected: {_lib.last_error()} (rc={rc})")
+    if kv0 is not None:
+        return m_new, V_new, lam_m, lam_var
+    return m_new, V_new
+
+
 # ------------------------------------------------------------------ inference
 def lambda_moments_star(xstar, xtilde, C, theta, K_tilde, K_tilde_inv, m, V, B, kernfun):
     """Predictive moments of lambda at test points (utils.py:1476-1500).  ``xstar`` may hold
@@ -1362,6 +1395,7 @@ def varGP(x, r, **kwargs):
                         lambda_m, lambda_var = moments_now()                                  # :1871
                         f_params['lambda0'] = lambda0_given_logA(f_params['logA'], r, lambda_m, lambda_var)  # :1874
                     f_mean = mean_f_given_lambda_moments(f_params, lambda_m, lambda_var)        # :1877
+                    fused_moments = False
                     if full_rank():
                         # fused Newton update in the original basis, then back to the eigenbasis
                         m_orig = m_b if _is_identity(B) else matmul(B, m_b)
@@ -1392,9 +1426,15 @@ def varGP(x, r, **kwargs):
                             L_kb, _, _, info_kb = cholesky(K_tilde_b)
                             if info_kb != 0:
                                 raise torch.linalg.LinAlgError(f"Estep: K_tilde is not positive definite (info={info_kb})")
-                            estep_factor[0] = (K_tilde_b, L_kb)
-                        m_b, V_b = _estep_given_factor(r, KKtilde_inv_b, m_b, f_params, f_mean, estep_factor[0][1])
-                    lambda_m, lambda_var = moments_now()                                        # :1884
+                            estep_factor[0] = (K_tilde_b, L_kb, matmul(KKtilde_inv_b, L_kb),
+                                               Kvec - torch.sum(K_b * KKtilde_inv_b, 1))
+                        # the update and the moments behind it (:1884) in one device call
+                        m_b, V_b, lambda_m, lambda_var = _estep_projected(r, KKtilde_inv_b, estep_factor[0][2],
+                                                                          estep_factor[0][1], m_b, f_params, f_mean,
+                                                                          kv0=estep_factor[0][3])
+                        fused_moments = True
+                    if not fused_moments:
+                        lambda_m, lambda_var = moments_now()                                    # :1884
                     f_mean = mean_f_given_lambda_moments(f_params, lambda_m, lambda_var)
                     tf = time.time()
                     f_params['lambda0'] = lambda0_given_logA(f_params['logA'], r, lambda_m, lambda_var)      # :1892

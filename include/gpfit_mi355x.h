@@ -242,6 +242,23 @@ int gpfit_potrf_append(gpfit_ctx* ctx, void* stream, double* L, int64_t ldl, dou
 int gpfit_estep(gpfit_ctx* ctx, void* stream, const double* K, int64_t ldk, int64_t N, const double* r,
                 const double* m, const double* f, double logA, double* m_new, double* V_new, int64_t ldv);
 
+/* The same Newton update in the basis in force when K~ is truncated or the inducing set is a subset (the else branch of
+ * varGP's E-step, utils.py:1880 -> Estep :1420-1439 with a = K K~^-1 in the B basis): with L = chol(K~_b) and
+ * aL = a L supplied by the caller (both fixed between two kernel rebuilds, i.e. over the nEstep updates of an EM
+ * iteration), s = A sqrt(f), Y = diag(s) aL:
+ *   W = I + Y^T Y = I + L^T G L = L_W L_W^T        (G = A^2 a^T diag(f) a, :1422)
+ *   V_new = P P^T, P = L L_W^-T                     (= solve(I + K~ G, K~), :1430)
+ *   m_new = L W^-1 aL^T u,  u = A^2 f o (a m) + A (r - f)   (= V_new (G m + g), :1431)
+ * a[N][lda], aL[N][ldal] (N x nb), L[nb][ldl] lower, r, f [N], m [nb] -> m_new [nb], V_new[nb][ldv] (full, symmetric).
+ * Optionally (all three pointers or none) the moments of lambda behind the update, which varGP evaluates next
+ * (lambda_moments, utils.py:1090, 1101): with kv0 = Kvec - rowsum(K o a) [N] (fixed between kernel rebuilds) and
+ * Z = aL L_W^-T,  lam_m = a m_new = Z (L_W^-1 aL^T u),  lam_var = kv0 + diag(a V_new a^T) = kv0 + row norms^2 of Z.
+ * One call, one synchronisation; returns LAPACK info if W is not positive definite. */
+int gpfit_estep_projected(gpfit_ctx* ctx, void* stream, const double* a, int64_t lda, const double* aL, int64_t ldal,
+                          const double* L, int64_t ldl, int64_t N, int64_t nb, const double* r, const double* m,
+                          const double* f, double logA, double* m_new, double* V_new, int64_t ldv, const double* kv0,
+                          double* lam_m_out, double* lam_var_out);
+
 /* One pass over the training points for the firing-rate parameters (mean_f_given_lambda_moments
  * utils.py:1126-1141, lambda0_given_logA :1215-1229, compute_loglikelihood with
  * compute_grad_for_f_params :1243-1255).  out_host[7]: lambda0 used (closed form if requested,

@@ -332,6 +332,76 @@ def test_estep_general_and_fused(gp):
             gp.Estep(r=r, KKtilde_inv=B, m=m_b, f_params=fp, f_mean=f, K_tilde=torch.diag(ev), alpha=0.5)
 
 
+def test_projected_estep_one_call(gp):
+    """gpfit_estep_projected (the E-step of the truncated / sparse regimes as one device call, utils.py:1420-1439 with
+    a = K K~^-1 in the B basis) against (i) the real reference's Estep in its eigenbasis (fixture G4: a = B, K~_b
+    diagonal), (ii) the product-by-product formulation it replaced and the textbook formula solve(I + K~ G, K~) in
+    torch fp64 on the CPU, on a sparse, truncated problem with ragged sizes (N = 1000 rows, 300 inducing points,
+    kept count not a multiple of anything), (iii) NaN rates: LAPACK info -> LinAlgError, as before."""
+    g = load_golden("g4_estep_N64.npz")
+    B, ev = T(g["B"]), T(g["eigvals"])
+    fp = {"logA": torch.tensor(float(g["logA"]), dtype=torch.float64)}
+    m_b = gp.matmul(B, T(g["m"]), transA=True)
+    L = torch.diag(torch.sqrt(ev))
+    m1, V1 = gp._estep_projected(T(g["r"]), B, gp.matmul(B, L), L, m_b, fp, T(g["f"]))
+    assert relerr(m1.cpu().numpy(), g["m_new_b"]) < 1e-9
+    assert relerr(V1.cpu().numpy(), g["V_new_b"]) < 1e-9
+    assert torch.equal(V1, V1.T)
+
+    N, nt, d = 1000, 300, 64
+    th = {k: torch.tensor(float(v), dtype=torch.float64) for k, v in syn.theta_eval().items()}
+    C, mask = gp.localker(th, UPPER, LOWER, 8)
+    X = torch.from_numpy(syn.stimuli(N, d)).cuda()[:, mask].contiguous()
+    Xt = X[:nt].contiguous()
+    Kt = gp.acosker(th, Xt, Xt, C=C)
+    K = gp.acosker(th, X, Xt, C=C)
+    w, U = torch.linalg.eigh(Kt)
+    keep = w > max(float(w.max()) * 1e-3, 1e-3)
+    Bk = U[:, keep].contiguous()
+    nb = int(keep.sum())
+    assert 0 < nb < nt and nb % 16 != 0
+    Ktb = torch.diag(w[keep])
+    a = gp.matmul(gp.matmul(K, Bk), torch.diag(1.0 / w[keep]))
+    r_np, _ = syn.cell_inputs(N)
+    r = torch.from_numpy(r_np).cuda()
+    rng = np.random.default_rng(3)
+    m_b = torch.from_numpy(0.3 * rng.standard_normal(nb)).cuda()
+    f = torch.from_numpy(np.exp(0.4 * rng.standard_normal(N)) * 0.6).cuda()
+    fp = {"logA": torch.tensor(float(np.log(0.4)), dtype=torch.float64)}
+    Lb, _, _, info = gp.cholesky(Ktb)
+    assert info == 0
+    m2, V2 = gp._estep_projected(r, a, gp.matmul(a, Lb), Lb, m_b, fp, f)
+    m3, V3 = gp._estep_given_factor(r, a, m_b, fp, f, Lb)
+    assert relerr(m2.cpu().numpy(), m3.cpu().numpy()) < 1e-11
+    assert relerr(V2.cpu().numpy(), V3.cpu().numpy()) < 1e-11
+    A = 0.4
+    ac, fc, rc_, mc, Kc = a.cpu(), f.cpu(), r.cpu(), m_b.cpu(), Ktb.cpu()
+    gvec = A * ac.T @ (rc_ - fc)
+    G = A * A * ac.T @ (ac * fc[:, None])
+    Vref = torch.linalg.solve(torch.eye(nb, dtype=torch.float64) + Kc @ G, Kc)
+    mref = Vref @ (G @ mc + gvec)
+    assert relerr(V2.cpu().numpy(), ((Vref + Vref.T) / 2).numpy()) < 1e-10
+    assert relerr(m2.cpu().numpy(), mref.numpy()) < 1e-10
+    assert torch.equal(V2, V2.T)
+
+    # ... and with the moments of lambda behind the update (what varGP evaluates next, utils.py:1884)
+    Kb = gp.matmul(K, Bk)
+    Kvec = gp.acosker(th, X, x2=None, C=C, diag=True)
+    m5, V5, lm, lv = gp._estep_projected(r, a, gp.matmul(a, Lb), Lb, m_b, fp, f, kv0=Kvec - torch.sum(Kb * a, 1))
+    assert torch.equal(m5, m2) and torch.equal(V5, V2)
+    lm_ref, lv_ref = gp.lambda_moments(X, Ktb, a, Kvec, Kb, C, m5, V5, th)
+    assert relerr(lm.cpu().numpy(), lm_ref.cpu().numpy()) < 1e-11
+    assert relerr(lv.cpu().numpy(), lv_ref.cpu().numpy()) < 1e-11
+
+    bad = f.clone()
+    bad[17] = float("nan")
+    with pytest.raises(torch.linalg.LinAlgError):
+        gp._estep_projected(r, a, gp.matmul(a, Lb), Lb, m_b, fp, bad)
+    # the workspace is in order after the failed call
+    m4, V4 = gp._estep_projected(r, a, gp.matmul(a, Lb), Lb, m_b, fp, f)
+    assert torch.equal(m4, m2) and torch.equal(V4, V2)
+
+
 def _fused_estep(gp, Kt, r, m, f, logA):
     from gaussian_processes_amd import _lib
     n = Kt.shape[0]
