@@ -32,6 +32,8 @@ columns does not reach below tau / 2, so it is grown anyway: 0.62 s per fit agai
 """
 from __future__ import annotations
 
+import math
+
 import torch
 
 
@@ -81,7 +83,12 @@ def _hash_matrix(rows, cols, device, dtype):
     return (x.to(dtype) * (1.0 / 2147483648.0) - 1.0).contiguous()
 
 
-def _kept_subspace(Q, Y, S, tol, a_out, matmul, cholesky, angle_tol, max_sign_iterations=40, log=None, gemm_into=None):
+# assumed lower bound of |x| at the start of the scaled sign iteration (see _kept_subspace)
+_SIGN_L0 = 1e-3
+
+
+def _kept_subspace(Q, Y, S, tol, a_out, matmul, cholesky, angle_tol, max_sign_iterations=40, log=None, gemm_into=None,
+                   scaled=True):
     """The kept invariant subspace WITHOUT the k x k eigendecomposition (24 ms of rocSOLVER at k = 1024: a third of a
     basis build at N = 8192, more than half at N = 4096), from GEMMs and Cholesky factorisations only.
 
@@ -119,29 +126,42 @@ def _kept_subspace(Q, Y, S, tol, a_out, matmul, cholesky, angle_tol, max_sign_it
     Sinv = matmul(Li, Li, transA=True)
     X = matmul(S - tau * eye, Sinv)
     X = (X + X.T) * 0.5
-    # Newton-Schulz: every eigenvalue x of X grows by 3/2 per step while small and then converges cubically to +-1.  The
-    # smallest |x_0| is half the relative distance of the nearest Ritz value from tau -- at least ~13 steps on these
-    # spectra -- so the convergence test (a host synchronisation) only starts there.
+    # Newton-Schulz, X <- X (3 I - X^2) / 2: every eigenvalue x of X grows by 3/2 per step while small and then converges
+    # cubically to +-1; the smallest |x_0| is half the relative distance of the nearest Ritz value from tau (1e-2 to
+    # 1e-5 on these spectra: 21-28 plain steps).  Scaled (Chen & Chow 2014): with every |x| in [l, 1], the step applied to
+    # c X, c^2 = 3 / (1 + l + l^2), maps l and 1 to the same value l' = c l (3 - c^2 l^2) / 2 and everything between
+    # them into [l', 1] -- small eigenvalues grow by up to 3 sqrt(3) / 2 = 2.6 per step instead of 1.5.  l is an
+    # ASSUMED bound (1e-3 to start with): eigenvalues below it still grow at the scaled rate and keep their sign (the
+    # map is positive on (0, sqrt 3) and c < sqrt 3), they only arrive later.  The convergence test (a host
+    # synchronisation) runs once the recurrence says l' = 1; if it fails, its own figure bounds the straggler from below
+    # (1 - x_min^2 <= ||X^2 - I||_F) and the scaled steps resume from there.
     its, settled = 0, False
     inplace = gemm_into is not None and not (k & 15)
+    lo = _SIGN_L0 if scaled else 1.0
     while its < max_sign_iterations:
         X2 = matmul(X, X)
-        if its >= 12:
+        if lo > 1.0 - 1e-9 and (scaled or its >= 12):
             dev2 = float(torch.linalg.matrix_norm(X2 - eye))      # Frobenius: sqrt(sum (x_i^2 - 1)^2)
             if dev2 < 1e-13 * k:
                 settled = True
                 break
+            if scaled:
+                # some |x| started below the assumed bound and is still on its way: 1 - x_min^2 <= dev2 bounds it from
+                # below (rigorously, once dev2 < 1), and the scaled steps resume from that bound
+                lo = math.sqrt(1.0 - dev2) if dev2 < 0.99 else 0.1
+        c = math.sqrt(3.0 / (1.0 + lo + lo * lo)) if lo < 1.0 else 1.0
         if inplace:
-            # X <- 1.5 X - 0.5 X X^2 as ONE product with beta (no temporaries; powers of a symmetric matrix commute, the
-            # rounding asymmetry of a step is 1e-16: symmetrised every eighth step and at the end)
+            # X <- 1.5 c X - 0.5 c^3 X X^2 as ONE product with beta (no temporaries; powers of a symmetric matrix commute,
+            # the rounding asymmetry of a step is 1e-16: symmetrised every eighth step and at the end)
             Xn = X.clone()
-            gemm_into(Xn, X, X2, alpha=-0.5, beta=1.5)
+            gemm_into(Xn, X, X2, alpha=-0.5 * c ** 3, beta=1.5 * c)
             X = Xn
             if (its & 7) == 7:
                 X = (X + X.T) * 0.5
         else:
-            X = matmul(X, 1.5 * eye - 0.5 * X2)
+            X = matmul(X, (1.5 * c) * eye - (0.5 * c ** 3) * X2)
             X = (X + X.T) * 0.5
+        lo = min(1.0, 0.5 * c * lo * (3.0 - c * c * lo * lo))
         its += 1
     X = (X + X.T) * 0.5
     if not settled:
@@ -300,7 +320,9 @@ def top_eigenpairs(K, tol, matmul, cholesky, k0=None, first_sweeps=None, max_swe
                                 # less (never below 30: the block's own bottom directions have to settle too)
                                 angle0 = warm_res / max(tau_est - a, 1e-300)
                                 info["start_angle"] = angle0
-                                need0 = min(_GAIN_NEEDED, max(30.0, _GAIN_NEEDED * 2.0 * angle0))
+                                # (a start block further out than a random one -- theta moved a lot -- gets up to one
+                                # sweep more than the cold plan rather than a second certificate pass)
+                                need0 = min(8.0 * _GAIN_NEEDED, max(30.0, _GAIN_NEEDED * 2.0 * angle0))
                                 warm_res = None        # (one plan per call: a grown or re-swept block is planned as before)
                             still = need0 * max(1.0, 1e-7 / angle_tol) / _filter_gain(applied, a, tau_est)
                             m = math.ceil(math.log(2.0 * max(still, 1.0)) / math.log(g))       # T_m(t) ~ g^m / 2

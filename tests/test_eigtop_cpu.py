@@ -116,6 +116,39 @@ def test_kept_eigenspace_without_a_dense_eigendecomposition():
     assert out is None or out[2].get("route") != "subspace"
 
 
+def test_scaled_sign_iteration_needs_fewer_steps_for_the_same_projector():
+    """The Newton-Schulz sign iteration of ``_kept_subspace`` with the Chen-Chow scaling (every step applied to c X,
+    c^2 = 3 / (1 + l + l^2) for an assumed lower bound l of |x|) against the plain iteration: the same count and basis,
+    in fewer steps -- also when the nearest Ritz value is CLOSER to the threshold than the assumed bound (the scaling
+    is then merely not optimal)."""
+    g = torch.Generator().manual_seed(4)
+    k, tol = 192, 1e-3
+    Z, _ = torch.linalg.qr(torch.randn(k, k, dtype=torch.float64, generator=g))
+    for nearest in (3e-2, 1e-5):                       # relative distance of the nearest eigenvalue from tau
+        theta = torch.logspace(0, -4.5, k, dtype=torch.float64)
+        tau = float(theta[0]) * tol
+        j = int(torch.argmin((theta - tau).abs()))
+        theta[j] = tau * (1 + nearest)
+        apart = ((theta - tau).abs() / tau >= nearest * 0.999)
+        theta = torch.where(apart, theta, tau * (1 + 2 * nearest) * torch.ones_like(theta))
+        S = (Z * theta) @ Z.T
+        S = (S + S.T) / 2
+        Q = torch.eye(k, dtype=torch.float64)
+        res = {}
+        for scaled in (False, True):
+            out = eigtop._kept_subspace(Q, S.clone(), S, tol, 0.0, cpu_matmul, cpu_cholesky, 1e-7, scaled=scaled)
+            assert out is not None
+            res[scaled] = out
+        nk = int((theta > tau).sum())
+        assert res[True]["n"] == res[False]["n"] == nk
+        assert res[True]["sign_iterations"] < res[False]["sign_iterations"], (nearest, res[True]["sign_iterations"],
+                                                                                 res[False]["sign_iterations"])
+        assert float((res[True]["B"] - res[False]["B"]).abs().max()) < 1e-7 / max(nearest, 1e-3) * 1e-3
+        top = Z[:, theta > tau]
+        P = top.T @ res[True]["B"]
+        assert float((P.T @ P - torch.eye(nk, dtype=torch.float64)).abs().max()) < 1e-8
+
+
 def test_warm_start_from_a_nearby_matrix_needs_fewer_sweeps_and_lands_on_the_same_space():
     """``start=info["state"]`` of a solve on K, handed to the solve of a perturbed K (what varGP does from one EM
     iteration to the next): fewer sweeps for the same certificate, the same count as eigh and the same space to rounding,

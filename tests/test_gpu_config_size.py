@@ -289,6 +289,35 @@ def test_fused_closures_on_tight_contexts_with_most_directions_kept(gp, nt, ntil
     assert np.abs(a - b).max() <= 1e-8 * np.abs(b).max(), (a, b)
 
 
+@pytest.mark.parametrize("nt,nb", [(300, 300), (640, 385), (1000, 128)])
+def test_projected_estep_on_a_tight_context(gp, nt, nb):
+    """gpfit_estep_projected on a freshly created context of capacity max(n_t, n_kept): every padded work matrix
+    (rows round_up(n_t, 128), columns round_up(n_kept, 128)) at or near the context's capacity, against the
+    product-by-product update and, with the moments, against lambda_moments."""
+    rng = np.random.default_rng(11)
+    Mx = rng.standard_normal((nb, nb + 40))
+    Ktb = T(Mx @ Mx.T / (nb + 40) + 0.05 * np.eye(nb))
+    a = T(rng.standard_normal((nt, nb)) / np.sqrt(nb))
+    m_b = T(0.2 * rng.standard_normal(nb))
+    f = T(np.exp(0.3 * rng.standard_normal(nt)))
+    r = T(rng.poisson(1.0, nt).astype(np.float64))
+    Kvec = T(2.0 + rng.random(nt))
+    Kb = gp.matmul(a, Ktb)
+    fp = {"logA": torch.tensor(float(np.log(0.5)), dtype=torch.float64)}
+    Lb, _, _, info = gp.cholesky(Ktb)
+    assert info == 0
+    aL = gp.matmul(a, Lb)
+    m_s, V_s = gp._estep_given_factor(r, a, m_b, fp, f, Lb)
+    lm_s, lv_s = gp.lambda_moments(None, Ktb, a, Kvec, Kb, None, m_s, V_s, None)
+    with fresh_pool(gp):
+        m_f, V_f, lm, lv = gp._estep_projected(r, a, aL, Lb, m_b, fp, f, kv0=Kvec - torch.sum(Kb * a, 1))
+        assert gp.get_engine(1, 1).n_max == max(nt, nb)
+    assert relerr(m_f.cpu().numpy(), m_s.cpu().numpy()) < 1e-10
+    assert relerr(V_f.cpu().numpy(), V_s.cpu().numpy()) < 1e-10
+    assert relerr(lm.cpu().numpy(), lm_s.cpu().numpy()) < 1e-10
+    assert relerr(lv.cpu().numpy(), lv_s.cpu().numpy()) < 1e-10
+
+
 def test_vargp_default_tolerance_N4096_matches_reference(gp):
     """A whole EM fit of the REAL reference at N = 4096 (d = 64, default EIGVAL_TOL: every iteration truncates) against
     the drop-in `varGP` -> `test`, whose basis at this size comes from the subspace solver without any dense
