@@ -272,9 +272,10 @@ int gpfit_fparam_eval(gpfit_ctx* c, void* stream, const double* lam_m, const dou
   }
   GP_CTX_ENTER(c, "gpfit_fparam_eval");
   hipStream_t s = (hipStream_t)stream;
+  // the seven results go straight to the context's pinned, device-mapped scalars (no copy command behind the kernel:
+  // the L-BFGS of the rate parameters calls this ~6 times per E-step and waits for every answer)
   GP_TRY(launch_fparam(lam_m, lam_var, r, (int)N, std::exp(logA), closed_form_lambda0, lambda0_in, f_out,
-                       c->scal + 32, s));
-  GP_HIP(hipMemcpyAsync(c->scal_host + 32, c->scal + 32, 7 * sizeof(double), hipMemcpyDeviceToHost, s));
+                       c->scal_host + 32, s));
   GP_HIP(hipStreamSynchronize(s));
   for (int i = 0; i < 7; ++i) out_host[i] = c->scal_host[32 + i];
   return 0;
