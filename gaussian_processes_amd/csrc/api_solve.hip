@@ -230,6 +230,7 @@ int gpfit_estep_projected(gpfit_ctx* c, void* stream, const double* a, int64_t l
   const double A = std::exp(logA);
   double *sv = c->yv, *u = c->bv, *t2 = c->tvec, *z1 = c->mpad, *z = c->rpad, *mo = c->hvec;
   double *Y = c->Tbuf, *Lp = c->Wbuf, *P = c->Abuf, *V = c->Zbuf, *part = c->TmpV, *aLp = c->LiVbuf, *Zm = c->Cos;
+  c->lv_valid = false; c->lv32_valid = false;   // the work matrices of the V chain are reused
   GP_HIP(hipMemsetAsync(c->info, 0, 4 * sizeof(int), s));
   GP_TRY(launch_estep_proj_rows(a, lda, k, m, f, r, n, nrows, A, sv, u, s));
   GP_TRY(launch_estep_proj_scale(aL, ldal, k, n, nrows, sv, u, Y, want_moments ? aLp : nullptr, ld, npc, part, s));
