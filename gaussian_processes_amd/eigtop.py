@@ -261,8 +261,13 @@ def top_eigenpairs(K, tol, matmul, cholesky, k0=None, first_sweeps=None, max_swe
     gen = torch.Generator(device=dev)
     gen.manual_seed(seed)
     # block: about twice the kept count of the fit's kernel matrices (500-540 at every N from 1024 up: the spectrum above
-    # the threshold is set by the stimulus dimension, not by N); below N = 2048 the caller takes the full eigh anyway
-    k = min(k0 or (min(1024, N // 2) if N >= 2048 else 512), N)
+    # the threshold is set by the stimulus dimension, not by N); below N = 1408 the caller takes the full eigh anyway
+    # largest block worth iterating on: half of N from N = 2048 up (beyond that a dense eigendecomposition is the better
+    # tool); two thirds below -- there the dense eigh (rocSOLVER: 29 / 36 / 43 ms at N = 1280 / 1536 / 1792) is slow
+    # against sweeps on so small a matrix, and half of N does not reach below the threshold (the kept count stays at
+    # 530-560 whatever N is)
+    kmax = N // 2 if N >= 2048 else (2 * N) // 3 // 128 * 128
+    k = min(k0 or min(1024, max(512, kmax // 128 * 128)), N)
     # How many sweeps before the first Rayleigh-Ritz check?  That k x k eigenproblem is the expensive step at the sizes
     # this solver serves (24 ms at k = 1024 against 3.3 ms per sweep at N = 8192), so the first check should pass.
     # Plain sweeps: a fixed 16 (8 below N = 4096), the measured need of the fit's kernel matrices.  Accelerated: planned
@@ -274,7 +279,7 @@ def top_eigenpairs(K, tol, matmul, cholesky, k0=None, first_sweeps=None, max_swe
         first_sweeps = (9 if accelerate else 16) if N >= 4096 else 8
     warm = None
     if (start is not None and basis == "subspace" and dynamic and tuple(start["Q"].shape) == (N, start["Q"].shape[1])
-            and start["Q"].shape[1] <= N // 2 and start["Q"].device == dev):
+            and start["Q"].shape[1] <= kmax and start["Q"].device == dev):
         warm = start
         k = int(start["Q"].shape[1])
         Q = start["Q"]
@@ -286,7 +291,7 @@ def top_eigenpairs(K, tol, matmul, cholesky, k0=None, first_sweeps=None, max_swe
     a_plan = None           # the same bound as the first (unshifted) sweep of this block gave it
     warm_res = None         # warm start: ||(I - Q Q^T) K B_old||_F of the old block and kept basis
     while True:
-        if k > N // 2:
+        if k > kmax:
             return None                      # not a truncation problem any more: a full eigh is the right tool
         shifts, applied = [], []
         i = 0
@@ -347,9 +352,9 @@ def top_eigenpairs(K, tol, matmul, cholesky, k0=None, first_sweeps=None, max_swe
         S = (S + S.T) * 0.5
         if basis == "subspace" and a_plan is not None:
             sub = _kept_subspace(Q, Y, S, tol, a_plan, matmul, cholesky, angle_tol, log=log, gemm_into=gemm_into)
-            if sub is not None and 4 * sub["n"] > 3 * k and k < N // 2:
+            if sub is not None and 4 * sub["n"] > 3 * k and k < kmax:
                 # nearly every direction of the block is kept: it does not reach below the threshold, grow it
-                grow = min(max(256, (k // 4 + 127) // 128 * 128), N // 2 - k, N - k)
+                grow = min(max(256, (k // 4 + 127) // 128 * 128), kmax - k, N - k)
                 Q = _cholqr(torch.cat([Q, torch.randn((N, grow), generator=gen, device=dev, dtype=dt)], dim=1), matmul, cholesky, 2)
                 if Q is None:
                     return None

@@ -890,7 +890,9 @@ def _stabilised_basis(K_tilde, route=None, start=None):
 
 import os as _os_mod
 _FORCE_EIGH = bool(_os_mod.environ.get("GPFIT_FORCE_EIGH"))   # tuning / A-B knob: always take the eigh route
-_EIGTOP_MIN_N = 2048   # below this the block (twice the kept count: ~1024 columns) is most of the matrix and the full eigh as fast
+_EIGTOP_MIN_N = 1408   # below this the block the kept count needs (530-570 kept whatever N is: 768-1024 columns) is most of the
+                       # matrix and the full eigh as fast (25-29 ms at N = 1152 / 1280 either way; at N = 1408 ... 2047 the
+                       # subspace route takes 10-15 ms on a block of up to 2N/3 against 32-50 ms, profiles/r04_small_n_basis.log)
 # What the truncated regime's basis B is made of at N >= 4096 (module global read at call time, like EIGVAL_TOL):
 #   "subspace"     (default) the canonical orthonormal basis of the kept EIGENSPACE: no dense eigendecomposition at
 #                  all; K_tilde_b = B^T K~ B is a dense n x n matrix.  Everything downstream is invariant under the
