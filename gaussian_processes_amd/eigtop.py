@@ -117,6 +117,40 @@ def _kept_subspace(Q, Y, S, tol, a_out, matmul, cholesky, angle_tol, max_sign_it
         w = S @ v
         v = w / torch.linalg.vector_norm(w)
     lam_max = float(v @ (S @ v))                    # (one host synchronisation for the whole power iteration)
+    if Q is None:
+        # S is the matrix itself, not the Rayleigh quotient matrix of a converged block: its best column is no
+        # eigenvector.  Iterate until the Rayleigh quotient (error = the square of the vector's) stands still, then
+        # CERTIFY it: lambda_max >= the quotient always, and a Cholesky factorisation of (1 + 1e-8) quotient I - S
+        # succeeds only if every eigenvalue lies below that -- so tau is the reference's to 1e-8 relative, or the route
+        # declines (a start vector nearly orthogonal to the top eigenvector makes the quotient stall at lambda_2 first;
+        # the certificate catches it, a power of S applied to the vector -- six normalised squarings -- gets it unstuck).
+        def settle(apply, lam0, blocks):
+            nonlocal v
+            lam_ = lam0
+            for _ in range(blocks):
+                for _ in range(8):
+                    w_ = apply(v)
+                    v = w_ / torch.linalg.vector_norm(w_)
+                nxt = float(v @ (S @ v))
+                still = abs(nxt - lam_) <= 1e-13 * abs(nxt)
+                lam_ = nxt
+                if still:
+                    break
+            return lam_
+
+        def certified(lam_):
+            _, _, _, info_c = cholesky((1.0 + 1e-8) * lam_ * eye - S)
+            return info_c == 0
+
+        lam_max = settle(lambda x: S @ x, lam_max, 8)
+        if not certified(lam_max):
+            M = S / torch.linalg.matrix_norm(S)
+            for _ in range(6):
+                M = matmul(M, M)
+                M = M / torch.linalg.matrix_norm(M)
+            lam_max = settle(lambda x: M @ x, lam_max, 40)
+            if not certified(lam_max):
+                return None
     tau = max(lam_max * tol, tol)
     if not (a_out < 0.55 * tau):
         return None                                 # the block does not reach well below the threshold: eigenpair route
@@ -171,12 +205,14 @@ def _kept_subspace(Q, Y, S, tol, a_out, matmul, cholesky, angle_tol, max_sign_it
     if n <= 0 or n >= k or abs(0.5 * (tr + k) - n) > 1e-6:
         return None
     P = 0.5 * (X + eye)
-    N = Q.shape[0]
-    M = matmul(P, matmul(Q, _hash_matrix(N, n, dev, dt), transA=True))          # P Q^T Omega   [k, n]
+    if Q is None:
+        M = matmul(P, _hash_matrix(k, n, dev, dt))                               # P Omega   [k, n]
+    else:
+        M = matmul(P, matmul(Q, _hash_matrix(Q.shape[0], n, dev, dt), transA=True))   # P Q^T Omega   [k, n]
     U = _cholqr(M, matmul, cholesky, 2)
     if U is None:
         return None
-    B = matmul(Q, U)
+    B = U if Q is None else matmul(Q, U)
     SU = matmul(S, U)
     Ktb = matmul(U, SU, transA=True)
     Ktb = (Ktb + Ktb.T) * 0.5
@@ -185,13 +221,42 @@ def _kept_subspace(Q, Y, S, tol, a_out, matmul, cholesky, angle_tol, max_sign_it
         return None
     Ktib = matmul(Lbi, Lbi, transA=True)
     Ktib = (Ktib + Ktib.T) * 0.5
-    R_out = matmul(Y, U) - matmul(Q, SU)
-    res = float(torch.linalg.matrix_norm(R_out))
-    angle = res / (tau - a_out)
+    if Q is None:
+        res = angle = 0.0                                                        # nothing leaves the whole space
+    else:
+        R_out = matmul(Y, U) - matmul(Q, SU)
+        res = float(torch.linalg.matrix_norm(R_out))
+        angle = res / (tau - a_out)
     if log is not None:
         log(f"eigtop: subspace route k {k} kept {n} sign iterations {its} residual leaving the block {res:.2e} angle bound {angle:.2e}")
     return {"B": B.contiguous(), "U": U, "K_tilde_b": Ktb, "K_tilde_inv_b": Ktib, "n": n, "tau": tau, "lam_max": lam_max,
             "angle": angle, "sign_iterations": its}
+
+
+def kept_eigenspace_dense(K, tol, matmul, cholesky, gemm_into=None, log=None):
+    """The kept eigenspace of a SMALL symmetric positive definite ``K`` (n up to ~1800) with no sweeps at all:
+    ``_kept_subspace`` with the whole space as its block (Q = I, S = K) -- the spectral projector of K itself by the
+    Cayley transform and the scaled sign iteration (two n^3 products per step, 12-15 steps), its trace the kept count,
+    ``B = orth(P Omega)`` the same canonical basis the sweeps route returns for that space.  For matrices whose kept
+    count (530-580 on the fit's kernel matrices, whatever n is) is a third or more of n a block iteration has nothing
+    to discard, and rocSOLVER's ``eigh`` takes 17 / 23 / 29 / 36 ms at n = 768 / 1024 / 1280 / 1536 against 3-7 ms for
+    this.  Returns ``(None, B, info)`` like ``top_eigenpairs(basis="subspace")`` (no ``state``: nothing to warm-start),
+    or ``None`` when the count is ambiguous or a factorisation fails (the caller takes the eigh)."""
+    n_true = K.shape[0]
+    if n_true % 16:
+        npad = (n_true + 15) // 16 * 16        # zero rows / columns: zero eigenvalues, far below any threshold
+        Kp = torch.zeros((npad, npad), device=K.device, dtype=K.dtype)
+        Kp[:n_true, :n_true] = K
+        K = Kp
+    S = (K + K.T) * 0.5
+    sub = _kept_subspace(None, None, S, tol, 0.0, matmul, cholesky, 1e-7, log=log, gemm_into=gemm_into)
+    if sub is None or sub["n"] >= n_true:
+        return None                            # (everything kept: the caller's identity route, not a truncation)
+    B = sub["B"][:n_true].contiguous()
+    info = {"k": int(S.shape[0]), "sweeps": 0, "products": 0, "grown": 0, "rr": 0, "warm": False, "angle": 0.0,
+            "n": sub["n"], "route": "subspace", "dense": True, "sign_iterations": sub["sign_iterations"],
+            "K_tilde_b": sub["K_tilde_b"], "K_tilde_inv_b": sub["K_tilde_inv_b"], "lam_max": sub["lam_max"]}
+    return None, B, info
 
 
 # what the kept directions must gain on everything the random start block left outside the block before the first
@@ -261,7 +326,7 @@ def top_eigenpairs(K, tol, matmul, cholesky, k0=None, first_sweeps=None, max_swe
     gen = torch.Generator(device=dev)
     gen.manual_seed(seed)
     # block: about twice the kept count of the fit's kernel matrices (500-540 at every N from 1024 up: the spectrum above
-    # the threshold is set by the stimulus dimension, not by N); below N = 1408 the caller takes the full eigh anyway
+    # the threshold is set by the stimulus dimension, not by N); below N = 1792 the caller takes kept_eigenspace_dense
     # largest block worth iterating on: half of N from N = 2048 up (beyond that a dense eigendecomposition is the better
     # tool); two thirds below -- there the dense eigh (rocSOLVER: 29 / 36 / 43 ms at N = 1280 / 1536 / 1792) is slow
     # against sweeps on so small a matrix, and half of N does not reach below the threshold (the kept count stays at

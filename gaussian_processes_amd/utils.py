@@ -817,9 +817,17 @@ def _stabilised_basis(K_tilde, route=None, start=None):
         # orthonormal basis of that space and the dense K~_b = B^T K~ B, no dense eigendecomposition at all;
         # "eigtop": its eigenvectors (one k x k eigh, k = 1024), same eigenvalues to 1e-14 and the same invariant
         # subspace to 1e-13 as the full eigh.  None: inconclusive -> the reference's own eigh.
+        want = want or ("subspace" if EIGTOP_BASIS == "subspace" else "eigtop")
+        if want == "subspace" and _DENSE_MIN_N <= n < _EIGTOP_MIN_N:
+            # small matrices: the spectral projector of K~ itself (Cayley transform + scaled sign iteration on the
+            # n x n matrix, no sweeps): 2.6 / 3.8 / 5.6 / 7.7 ms at n = 512 / 1024 / 1280 / 1536 against 12 / 22 / 29 /
+            # 35 ms for rocSOLVER's eigh; the same canonical basis as the sweeps route gives for that space
+            top = eigtop.kept_eigenspace_dense(K_tilde, EIGVAL_TOL, matmul, cholesky, gemm_into=gemm_into)
+            if top is None:
+                return None
+            return "subspace", (top[1], top[1], top[2]["K_tilde_b"], top[2]["K_tilde_inv_b"])
         if n < _EIGTOP_MIN_N:
             return None
-        want = want or ("subspace" if EIGTOP_BASIS == "subspace" else "eigtop")
         top = eigtop.top_eigenpairs(K_tilde, EIGVAL_TOL, matmul, cholesky,
                                     basis="subspace" if want == "subspace" else "eigenvectors", gemm_into=gemm_into,
                                     start=start if want == "subspace" else None)
@@ -890,9 +898,11 @@ def _stabilised_basis(K_tilde, route=None, start=None):
 
 import os as _os_mod
 _FORCE_EIGH = bool(_os_mod.environ.get("GPFIT_FORCE_EIGH"))   # tuning / A-B knob: always take the eigh route
-_EIGTOP_MIN_N = 1408   # below this the block the kept count needs (530-570 kept whatever N is: 768-1024 columns) is most of the
-                       # matrix and the full eigh as fast (25-29 ms at N = 1152 / 1280 either way; at N = 1408 ... 2047 the
-                       # subspace route takes 10-15 ms on a block of up to 2N/3 against 32-50 ms, profiles/r04_small_n_basis.log)
+_EIGTOP_MIN_N = 1792   # from here up the kept eigenspace comes from block subspace sweeps (warm-started: 10.4 ms at N = 1792,
+                       # 10.8 at 2048, 11.7 at 2560); below, down to _DENSE_MIN_N, from the spectral projector of K~ itself
+                       # (no sweeps: 9.6 ms at N = 1792, 11.4 at 2048, 22 at 2560) -- profiles/r04_small_n_basis.log.  The
+                       # kept count is 530-580 whatever N is, so below ~1800 a block iteration has nothing to discard.
+_DENSE_MIN_N = 256     # below this the reference's own eigh (a few ms)
 # What the truncated regime's basis B is made of at N >= 4096 (module global read at call time, like EIGVAL_TOL):
 #   "subspace"     (default) the canonical orthonormal basis of the kept EIGENSPACE: no dense eigendecomposition at
 #                  all; K_tilde_b = B^T K~ B is a dense n x n matrix.  Everything downstream is invariant under the

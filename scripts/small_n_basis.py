@@ -1,4 +1,5 @@
-"""eigh against the subspace route for inducing sets between 1024 and 2048."""
+"""rocSOLVER's eigh against the two eigh-free routes for the kept eigenspace of small inducing sets
+(profiles/r04_small_n_basis.log): `python scripts/small_n_basis.py`."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -18,23 +19,28 @@ def timeit(fn, reps=3):
         torch.cuda.synchronize(); t0 = time.perf_counter(); out = fn(); torch.cuda.synchronize()
         best = min(best, time.perf_counter() - t0)
     return best * 1e3, out
-for NT in (1024, 1152, 1280, 1408, 1536, 1664, 1792, 1920, 2048, 2100):
+for NT in (256, 384, 512, 640, 768, 1000, 1024, 1280, 1408, 1536, 1792, 2048, 2100, 2560):
     K = kt(NT)
     t_eigh, (w, U) = timeit(lambda: torch.linalg.eigh(K))
     keep = int((w > max(float(w[-1]) * 1e-4, 1e-4)).sum())
     line = f"ntilde {NT}: eigh {t_eigh:.1f} ms kept {keep}"
-    for k0 in (None,):
-        kk = None
-        t_c, out = timeit(lambda: eigtop.top_eigenpairs(K, 1e-4, gp.matmul, gp.cholesky, k0=kk, basis="subspace", gemm_into=gp.gemm_into))
-        if out is None or out[0] is not None:
-            line += f" | cold {t_c:.1f} ms -> " + ("declined" if out is None else f"eigenpairs k {out[2]['k']} kept {out[2]['n']}")
-            continue
-        info = out[2]
-        K2 = kt(NT, 1.003)
-        t_w, out2 = timeit(lambda: eigtop.top_eigenpairs(K2, 1e-4, gp.matmul, gp.cholesky, k0=kk, basis="subspace", gemm_into=gp.gemm_into, start=info["state"]))
-        ok2 = out2 is not None and out2[0] is None
-        P = U[:, -info['n']:].T @ out[1]
-        err = float((P.T @ P - torch.eye(info['n'], device=dev, dtype=torch.float64)).abs().max())
-        line += f" [subspace dist {err:.1e}]"
-        line += f" | k {info['k']}: cold {t_c:.1f} ms ({info['sweeps']} sw, kept {info['n']}), warm {t_w:.1f} ms ({out2[2]['sweeps'] if ok2 else 'x'} sw)"
+    t_d, out = timeit(lambda: eigtop.kept_eigenspace_dense(K, 1e-4, gp.matmul, gp.cholesky, gemm_into=gp.gemm_into))
+    if out is None:
+        line += f" | dense projector {t_d:.1f} ms -> declined"
+    else:
+        n = out[2]["n"]
+        if n == keep and 0 < n < NT:
+            P = U[:, -n:].T @ out[1]
+            err = float((P.T @ P - torch.eye(n, device=dev, dtype=torch.float64)).abs().max())
+        else:
+            err = float("nan")
+        line += f" | dense projector {t_d:.1f} ms (kept {n}, {out[2]['sign_iterations']} sign steps, subspace dist {err:.1e})"
+    if NT >= 1408:
+        t_c, o = timeit(lambda: eigtop.top_eigenpairs(K, 1e-4, gp.matmul, gp.cholesky, basis="subspace", gemm_into=gp.gemm_into))
+        if o is not None and o[0] is None:
+            K2 = kt(NT, 1.003)
+            t_w, o2 = timeit(lambda: eigtop.top_eigenpairs(K2, 1e-4, gp.matmul, gp.cholesky, basis="subspace", gemm_into=gp.gemm_into, start=o[2]["state"]))
+            line += f" | sweeps k {o[2]['k']}: cold {t_c:.1f} ms ({o[2]['sweeps']} sw), warm {t_w:.1f} ms ({o2[2]['sweeps'] if o2 is not None and o2[0] is None else 'x'} sw)"
+            if out is not None:
+                line += f", canonical bases differ by {float((o[1] - out[1]).abs().max()):.1e}"
     print(line, flush=True)

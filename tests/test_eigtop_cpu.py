@@ -149,6 +149,50 @@ def test_scaled_sign_iteration_needs_fewer_steps_for_the_same_projector():
         assert float((P.T @ P - torch.eye(nk, dtype=torch.float64)).abs().max()) < 1e-8
 
 
+def test_dense_projector_route_for_small_matrices():
+    """``kept_eigenspace_dense``: the kept eigenspace from the spectral projector of K itself (no sweeps) -- the count of
+    eigh, the same space to rounding, the same canonical basis as the sweeps route returns for it (also when the size
+    is not a multiple of the GEMM's K step and K is padded), dense K~_b with the kept eigenvalues; everything kept or an
+    eigenvalue on the threshold: declines."""
+    tol = 1e-4
+    for n in (900, 512):
+        K, lam, Q = kernel_like_matrix(n)
+        K = (K + K.T) / 2
+        w, U = torch.linalg.eigh(K)
+        keep = w > max(float(w[-1]) * tol, tol)
+        nk = int(keep.sum())
+        out = eigtop.kept_eigenspace_dense(K, tol, cpu_matmul, cpu_cholesky)
+        assert out is not None and out[0] is None
+        B, info = out[1], out[2]
+        assert B.shape == (n, nk) and info["n"] == nk and info["route"] == "subspace" and info["sweeps"] == 0
+        assert "state" not in info
+        eye = torch.eye(nk, dtype=torch.float64)
+        P = U[:, keep].T @ B
+        assert float((P.T @ P - eye).abs().max()) < 1e-10 and float((B.T @ B - eye).abs().max()) < 1e-12
+        assert float(((torch.linalg.eigvalsh(info["K_tilde_b"]) - w[keep]).abs() / w[keep]).max()) < 1e-10
+        assert float((info["K_tilde_inv_b"] @ info["K_tilde_b"] - eye).abs().max()) < 1e-8
+        assert abs(info["lam_max"] - float(w[-1])) <= 1e-12 * float(w[-1])
+        sw = eigtop.top_eigenpairs(K, tol, cpu_matmul, cpu_cholesky, k0=160, basis="subspace")
+        assert sw is not None and sw[0] is None
+        assert float((sw[1] - B).abs().max()) < 1e-6
+    # a top eigenvalue that is NOT well separated: the power iteration for lambda_max runs until the Rayleigh quotient
+    # stands still (tau = lambda_max * tol decides the count)
+    g = torch.Generator().manual_seed(5)
+    Qm, _ = torch.linalg.qr(torch.randn(300, 300, dtype=torch.float64, generator=g))
+    lam = torch.logspace(0, -7, 300, dtype=torch.float64)
+    lam[1] = 0.97
+    Km = (Qm * lam) @ Qm.T
+    out = eigtop.kept_eigenspace_dense((Km + Km.T) / 2, 1e-3, cpu_matmul, cpu_cholesky)
+    assert out is not None and out[2]["n"] == int((lam > 1e-3).sum()) and abs(out[2]["lam_max"] - 1.0) < 1e-10
+    # nothing dropped / an eigenvalue on the threshold: not this route's business
+    Kf = (Qm * torch.linspace(1.0, 2.0, 300, dtype=torch.float64)) @ Qm.T
+    assert eigtop.kept_eigenspace_dense((Kf + Kf.T) / 2, 1e-4, cpu_matmul, cpu_cholesky) is None
+    lam2 = torch.logspace(0, -7, 300, dtype=torch.float64)
+    lam2[40] = 1e-3 * (1 + 1e-14)
+    Ka = (Qm * lam2) @ Qm.T
+    assert eigtop.kept_eigenspace_dense((Ka + Ka.T) / 2, 1e-3, cpu_matmul, cpu_cholesky) is None
+
+
 def test_warm_start_from_a_nearby_matrix_needs_fewer_sweeps_and_lands_on_the_same_space():
     """``start=info["state"]`` of a solve on K, handed to the solve of a perturbed K (what varGP does from one EM
     iteration to the next): fewer sweeps for the same certificate, the same count as eigh and the same space to rounding,

@@ -930,14 +930,65 @@ def test_closure_in_the_subspace_basis_equals_the_eigh_basis(gp):
     assert np.abs(g0 - g1).max() <= 1e-8 * np.abs(g1).max(), (g0, g1)
 
 
+@pytest.mark.parametrize("N", [1000, 1536])
+def test_small_truncated_basis_from_the_spectral_projector(gp, N):
+    """Below N = 1792 the kept eigenspace comes from the spectral projector of K~ itself (eigtop.kept_eigenspace_dense:
+    certified lambda_max, Cayley transform, scaled sign iteration on the N x N matrix, canonical basis) -- no sweeps,
+    no eigh: same count and space as torch.linalg.eigh, K~_b dense with the kept eigenvalues, the same bits twice, the
+    same canonical basis as the sweeps route gives for that space, and the fused truncated closure on it equal to the
+    one on eigh's eigenvectors.  N = 1000: not a multiple of the GEMM's K step (K~ padded inside)."""
+    from gaussian_processes_amd import eigtop
+    d = 256
+    th = {k: torch.tensor(float(v), dtype=torch.float64) for k, v in syn.theta0().items()}
+    X = torch.from_numpy(syn.stimuli(N, d)).cuda()
+    C, mask = gp.localker(th, UPPER, LOWER, 16)
+    Xm = X[:, mask].contiguous()
+    K = gp.acosker(th, Xm, Xm, C=C)
+    w, U = torch.linalg.eigh(K)
+    keep = w > max(float(w[-1]) * gp.EIGVAL_TOL, gp.EIGVAL_TOL)
+    nk = int(keep.sum())
+    assert 0 < nk < N
+    gp._BASIS.__dict__.pop("regime", None)
+    _, B, Kb, Kib = gp._stabilised_basis(K)
+    assert gp._BASIS.route == "subspace" and gp._BASIS.state is None and B.shape == (N, nk)
+    eye = torch.eye(nk, dtype=torch.float64, device="cuda")
+    P = U[:, keep].T @ B
+    assert float((P.T @ P - eye).abs().max()) < 1e-10 and float((B.T @ B - eye).abs().max()) < 1e-12
+    assert float(((torch.linalg.eigvalsh(Kb) - w[keep]).abs() / w[keep]).max()) < 1e-11
+    assert float((Kib @ Kb - eye).abs().max()) < 1e-9
+    _, B2, Kb2, _ = gp._stabilised_basis(K, route="subspace")
+    assert torch.equal(B2, B) and torch.equal(Kb2, Kb)
+    if N >= 1408:
+        sw = eigtop.top_eigenpairs(K, gp.EIGVAL_TOL, gp.matmul, gp.cholesky, basis="subspace", gemm_into=gp.gemm_into)
+        assert sw is not None and sw[0] is None and float((sw[1] - B).abs().max()) < 1e-7
+    # the truncated closure is invariant under the choice of an orthonormal basis of the kept space
+    r_np, m_np = syn.cell_inputs(N)
+    r = torch.from_numpy(r_np).cuda()
+    f_params = {"logA": torch.tensor(syn.F_PARAMS["logA"], dtype=torch.float64),
+                "lambda0": torch.tensor(syn.F_PARAMS["lambda0"], dtype=torch.float64)}
+    m_orig = torch.from_numpy(m_np).cuda()
+    res = []
+    for Bx in (B, U[:, keep].contiguous()):
+        m_b = gp.matmul(Bx, m_orig, transA=True)
+        V_b = 0.5 * gp.matmul(Bx, gp.matmul(K, Bx), transA=True)
+        V_b = (V_b + V_b.T) / 2
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            loss, grad = gp._closure_projected(th, (LOWER, UPPER), 16, X, r, Bx, m_b, V_b, f_params)
+        res.append((float(loss), np.array([grad[k] for k in KEYS])))
+    (l0, g0), (l1, g1) = res
+    assert abs(l0 - l1) <= 1e-10 * abs(l1), (l0, l1)
+    assert np.abs(g0 - g1).max() <= 1e-8 * np.abs(g1).max(), (g0, g1)
+
+
 @pytest.mark.parametrize("N", [4096, 1536])
 def test_vargp_with_the_subspace_basis_tracks_the_eigh_route(gp, N):
     """A whole fit at the reference's default tolerance at N = 4096 (about 520 of 4096 directions kept, the
     count moving with theta from one EM iteration to the next), once with the kept eigenpairs from the
     subspace solver and once with torch.linalg.eigh forced: same kept counts, log-marginal track to 1e-8, final
     theta to 1e-7, predictions to 1e-7 (the subspace solver's B is an orthonormal basis of the kept eigenspace, not
-    its eigenvectors; nothing downstream depends on which basis of that space it is).  N = 1536: the smallest sizes the
-    subspace route serves (from 1408), where its block is two thirds of the matrix (1024 columns for ~547 kept)."""
+    its eigenvectors; nothing downstream depends on which basis of that space it is).  N = 1536: below 1792 the kept
+    space comes from the spectral projector of K~ itself (no sweeps, nothing to warm-start)."""
     d = 256
     dev = torch.device("cuda:0")
     X = T(syn.stimuli(N, d)).to(dev)
