@@ -4,7 +4,8 @@ Same function names, argument meaning and error behaviour as the reference for t
 SURVEY.md section 8 scopes (``localker``, ``acosker``, ``lambda_moments``, ``compute_KL_div``,
 ``Estep``, ``varGP``, ``test`` ...), but every kernel / factorisation / solve runs in the
 hand-written HIP library ``libgpfit_mi355x.so`` through ctypes.  torch supplies device
-memory, streams and (for the rank decision only) ``torch.linalg.eigh``.
+memory, streams, the L-BFGS drivers and, for the eigen-stabilisation of matrices below 256 rows or whenever the
+eigh-free routes decline (an eigenvalue on the threshold), ``torch.linalg.eigh``.
 
 There is no CPU fallback: without a GPU or without the built library every entry point raises.
 Out of scope (SURVEY.md section 2 rows 10-14,16-19): plotting, persistence (``save_model`` / ``load_model``: the
