@@ -88,7 +88,7 @@ _SIGN_L0 = 1e-3
 
 
 def _kept_subspace(Q, Y, S, tol, a_out, matmul, cholesky, angle_tol, max_sign_iterations=40, log=None, gemm_into=None,
-                   scaled=True):
+                   scaled=True, k_true=None):
     """The kept invariant subspace WITHOUT the k x k eigendecomposition (24 ms of rocSOLVER at k = 1024: a third of a
     basis build at N = 8192, more than half at N = 4096), from GEMMs and Cholesky factorisations only.
 
@@ -108,6 +108,7 @@ def _kept_subspace(Q, Y, S, tol, a_out, matmul, cholesky, angle_tol, max_sign_it
     iteration does not settle (a Ritz value within ~1e-7 tau of the threshold: the count is ambiguous, as in the
     eigenpair route) or a factorisation fails; the caller then takes the eigenpair route."""
     k = S.shape[0]
+    k_true = k if k_true is None else k_true      # rows of the matrix proper when S carries zero padding (Q is None)
     dev, dt = S.device, S.dtype
     eye = torch.eye(k, device=dev, dtype=dt)
     # lambda_max(S)
@@ -202,7 +203,13 @@ def _kept_subspace(Q, Y, S, tol, a_out, matmul, cholesky, angle_tol, max_sign_it
         return None
     tr = float(torch.trace(X))
     n = int(round(0.5 * (tr + k)))
-    if n <= 0 or n >= k or abs(0.5 * (tr + k) - n) > 1e-6:
+    if abs(0.5 * (tr + k) - n) > 1e-6:
+        return None
+    if Q is None and n >= k_true:
+        # the projector is the identity on the matrix proper: every eigenvalue lies above the (certified) threshold --
+        # the exact version of the caller's all-kept proof, not a truncation
+        return {"n": k_true, "all_kept": True, "tau": tau, "lam_max": lam_max, "sign_iterations": its}
+    if n <= 0 or n >= k:
         return None
     P = 0.5 * (X + eye)
     if Q is None:
@@ -240,8 +247,10 @@ def kept_eigenspace_dense(K, tol, matmul, cholesky, gemm_into=None, log=None):
     ``B = orth(P Omega)`` the same canonical basis the sweeps route returns for that space.  For matrices whose kept
     count (530-580 on the fit's kernel matrices, whatever n is) is a third or more of n a block iteration has nothing
     to discard, and rocSOLVER's ``eigh`` takes 17 / 23 / 29 / 36 ms at n = 768 / 1024 / 1280 / 1536 against 3-7 ms for
-    this.  Returns ``(None, B, info)`` like ``top_eigenpairs(basis="subspace")`` (no ``state``: nothing to warm-start),
-    or ``None`` when the count is ambiguous or a factorisation fails (the caller takes the eigh)."""
+    this.  Returns ``(None, B, info)`` like ``top_eigenpairs(basis="subspace")`` (no ``state``: nothing to warm-start);
+    ``(None, None, info)`` with ``info["all_kept"]`` when the projector is the identity, i.e. EVERY eigenvalue lies above
+    the threshold -- the exact form of the all-kept proof the caller first attempts with norm bounds; or ``None`` when
+    the count is ambiguous or a factorisation fails (the caller takes the eigh)."""
     n_true = K.shape[0]
     if n_true % 16:
         npad = (n_true + 15) // 16 * 16        # zero rows / columns: zero eigenvalues, far below any threshold
@@ -249,9 +258,13 @@ def kept_eigenspace_dense(K, tol, matmul, cholesky, gemm_into=None, log=None):
         Kp[:n_true, :n_true] = K
         K = Kp
     S = (K + K.T) * 0.5
-    sub = _kept_subspace(None, None, S, tol, 0.0, matmul, cholesky, 1e-7, log=log, gemm_into=gemm_into)
-    if sub is None or sub["n"] >= n_true:
-        return None                            # (everything kept: the caller's identity route, not a truncation)
+    sub = _kept_subspace(None, None, S, tol, 0.0, matmul, cholesky, 1e-7, log=log, gemm_into=gemm_into, k_true=n_true)
+    if sub is None:
+        return None
+    if sub.get("all_kept"):
+        # nothing is dropped: an exact all-kept proof (the caller's identity route), not a truncation
+        return None, None, {"n": n_true, "all_kept": True, "route": "identity", "lam_max": sub["lam_max"],
+                            "sign_iterations": sub["sign_iterations"]}
     B = sub["B"][:n_true].contiguous()
     info = {"k": int(S.shape[0]), "sweeps": 0, "products": 0, "grown": 0, "rr": 0, "warm": False, "angle": 0.0,
             "n": sub["n"], "route": "subspace", "dense": True, "sign_iterations": sub["sign_iterations"],

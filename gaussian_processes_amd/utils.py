@@ -826,6 +826,8 @@ def _stabilised_basis(K_tilde, route=None, start=None):
             top = eigtop.kept_eigenspace_dense(K_tilde, EIGVAL_TOL, matmul, cholesky, gemm_into=gemm_into)
             if top is None:
                 return None
+            if top[1] is None:
+                return "all-kept", None      # the projector is the identity: an exact all-kept proof (identity route)
             return "subspace", (top[1], top[1], top[2]["K_tilde_b"], top[2]["K_tilde_inv_b"])
         if n < _EIGTOP_MIN_N:
             return None
@@ -854,6 +856,9 @@ def _stabilised_basis(K_tilde, route=None, start=None):
     if route is not None:
         if route == "identity":
             kept, L, Li = _all_eigenvalues_kept(K_tilde)
+            if not kept and L is not None:
+                got = truncated_basis("subspace")     # small matrices: the exact count where the norm bounds are not enough
+                kept = got is not None and got[0] == "all-kept"
             out = identity_basis(Li) if kept else None
             if kept:
                 _BASIS.factor = (L, Li)
@@ -876,23 +881,28 @@ def _stabilised_basis(K_tilde, route=None, start=None):
         # skips the Cholesky + inverse + norms of the all-kept proof (~25 ms at N = 8192).
         hints = _BASIS.__dict__.setdefault("regime", {})
         key = (n, float(EIGVAL_TOL))
+        exact_all = False        # the small-matrix projector found every eigenvalue above the threshold
         if hints.get(key) == "truncated":
             got = truncated_basis()
-            if got is not None:
+            if got is not None and got[0] != "all-kept":
                 _BASIS.route = got[0]
                 return got[1]
+            exact_all = got is not None
         kept, L, Li = _all_eigenvalues_kept(K_tilde)
-        if kept:
+        if not kept and not exact_all and hints.get(key) != "truncated":
+            got = truncated_basis()
+            if got is not None and got[0] != "all-kept":
+                hints[key] = "truncated"
+                _BASIS.route = got[0]
+                return got[1]
+            exact_all = got is not None
+        if (kept or exact_all) and L is not None:
+            # proved by the norm bounds of _all_eigenvalues_kept or, where those are inconclusive on a small matrix
+            # (BASELINE configs[0]: lambda_min within 2 % of the threshold), by the exact count of the spectral projector
             hints[key] = "full"
             _BASIS.route = "identity"
             _BASIS.factor = (L, Li)      # K~ = L L^T, L^-1: kept by varGP for the closed loop (extend_inducing_set)
             return identity_basis(Li)
-        if hints.get(key) != "truncated":
-            got = truncated_basis()
-            if got is not None:
-                hints[key] = "truncated"
-                _BASIS.route = got[0]
-                return got[1]
     _BASIS.route = "eigh"
     return eigh_basis()
 

@@ -184,9 +184,12 @@ def test_dense_projector_route_for_small_matrices():
     Km = (Qm * lam) @ Qm.T
     out = eigtop.kept_eigenspace_dense((Km + Km.T) / 2, 1e-3, cpu_matmul, cpu_cholesky)
     assert out is not None and out[2]["n"] == int((lam > 1e-3).sum()) and abs(out[2]["lam_max"] - 1.0) < 1e-10
-    # nothing dropped / an eigenvalue on the threshold: not this route's business
-    Kf = (Qm * torch.linspace(1.0, 2.0, 300, dtype=torch.float64)) @ Qm.T
-    assert eigtop.kept_eigenspace_dense((Kf + Kf.T) / 2, 1e-4, cpu_matmul, cpu_cholesky) is None
+    # nothing dropped: reported as such (an exact all-kept proof); an eigenvalue on the threshold: declines
+    for nf in (300, 304):                                   # padded inside / a multiple of the K step as it is
+        Qf, _ = torch.linalg.qr(torch.randn(nf, nf, dtype=torch.float64, generator=g))
+        Kf = (Qf * torch.linspace(1.0, 2.0, nf, dtype=torch.float64)) @ Qf.T
+        allk = eigtop.kept_eigenspace_dense((Kf + Kf.T) / 2, 1e-4, cpu_matmul, cpu_cholesky)
+        assert allk is not None and allk[1] is None and allk[2]["all_kept"] and allk[2]["n"] == nf
     lam2 = torch.logspace(0, -7, 300, dtype=torch.float64)
     lam2[40] = 1e-3 * (1 + 1e-14)
     Ka = (Qm * lam2) @ Qm.T
