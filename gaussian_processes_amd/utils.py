@@ -794,7 +794,8 @@ def _stabilised_basis(K_tilde, route=None, start=None):
     everything the reference computes downstream is basis-invariant, so the
     identity is used: ``B = I``, ``K_tilde_b = K~``, ``K_tilde_inv_b = L^-T L^-1`` -- no ``eigh``
     (0.67 s at N = 8192, five of them in a four-iteration fit).  When eigenvalues are truncated and
-    N >= 4096, the kept eigenpairs come from block subspace iteration (``eigtop.top_eigenpairs``) and the
+    N >= 256, the kept eigenspace comes from ``eigtop`` (block subspace iteration from N = 1792, the spectral projector of K~
+    itself below) and the
     first return value holds only those columns; otherwise, and whenever that solver declines, the
     reference's own eigendecomposition + truncation.  Every route is a deterministic function of K~, so
     ``test(at_iteration=...)`` rebuilds the basis the tracked ``(m_b, V_b)`` were expressed in.
@@ -914,7 +915,7 @@ _EIGTOP_MIN_N = 1792   # from here up the kept eigenspace comes from block subsp
                        # (no sweeps: 9.6 ms at N = 1792, 11.4 at 2048, 22 at 2560) -- profiles/r04_small_n_basis.log.  The
                        # kept count is 530-580 whatever N is, so below ~1800 a block iteration has nothing to discard.
 _DENSE_MIN_N = 256     # below this the reference's own eigh (a few ms)
-# What the truncated regime's basis B is made of at N >= 4096 (module global read at call time, like EIGVAL_TOL):
+# What the truncated regime's basis B is made of at N >= 256 (module global read at call time, like EIGVAL_TOL):
 #   "subspace"     (default) the canonical orthonormal basis of the kept EIGENSPACE: no dense eigendecomposition at
 #                  all; K_tilde_b = B^T K~ B is a dense n x n matrix.  Everything downstream is invariant under the
 #                  choice of an orthonormal basis of that space (the reference's own formulas only use B^T B = I and the
@@ -1239,7 +1240,7 @@ def varGP(x, r, **kwargs):
     Deviations from the reference's ``fit_model``, both additive or opt-out:
     * ``final_kernel['eigvecs']`` (utils.py:2241: the N x N eigenvector matrix of K~) is ``None`` when every
       eigenvalue was kept (no eigendecomposition is computed on that route) and holds only the kept columns when
-      the subspace solver built the basis (N >= 4096, truncated spectrum); ``fit_parameters['full_eigvecs'] =
+      the subspace solver built the basis (N >= 256, truncated spectrum); ``fit_parameters['full_eigvecs'] =
       True`` asks for the reference's full matrix (one ``torch.linalg.eigh`` of the final K~ at the end of the fit).
     * extra keys: ``fit_model['basis_route']`` and ``values_track['variation_par_track']['basis_route']``
       (``'identity'`` / ``'eigtop'`` / ``'eigh'`` per tracked iteration): the route that built the basis ``(m_b,
