@@ -38,7 +38,9 @@ if [ "$part" = "all" ] || [ "$part" = "c" ]; then
 for n in 1024 2048 4096 6144 8192 12288 16384 32768; do python bench.py --n $n --steps 6 --warmup 2 --no-cpu-baseline --no-in-flight 2>/dev/null >> $out/${tag}_size_sweep.jsonl; done
 : > $out/${tag}_whole_fits.log
 python examples/one_cell_fit.py --n 512 --d 64 >> $out/${tag}_whole_fits.log 2>&1
+python examples/one_cell_fit.py --n 1024 --d 256 >> $out/${tag}_whole_fits.log 2>&1
 python examples/one_cell_fit.py --n 2048 --d 256 >> $out/${tag}_whole_fits.log 2>&1
+python examples/one_cell_fit.py --n 2500 --ntilde 1536 --d 256 --maxiter 10 --nestep 5 --nmstep 6 >> $out/${tag}_whole_fits.log 2>&1
 python examples/one_cell_fit.py --n 4096 --d 256 >> $out/${tag}_whole_fits.log 2>&1
 python examples/one_cell_fit.py --n 8192 --d 256 >> $out/${tag}_whole_fits.log 2>&1
 python examples/one_cell_fit.py --n 8192 --d 256 --tol 1e-14 >> $out/${tag}_whole_fits.log 2>&1
