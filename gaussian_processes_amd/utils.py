@@ -1327,6 +1327,23 @@ def varGP(x, r, **kwargs):
         Mb = matmul(B_, matmul(M, B_), transA=True)
         return Mb
 
+    rate_cache = [None]
+
+    def lambda0_and_rate():
+        """``lambda0_given_logA`` (:1874, :1934) and, from the same pass over the training points, the rate at that
+        ``(logA, lambda0)`` -- what ``mean_f_given_lambda_moments`` is asked for next (:1877, :1958) with the very same
+        inputs: the kernel computes both, so the second call (one launch and one wait per E-step) is answered from here."""
+        f, out = _fparam_eval(lambda_m, lambda_var, r, f_params['logA'], True)
+        rate_cache[0] = (lambda_m, lambda_var, _scalar(f_params['logA']), out[0], f)
+        return torch.tensor(out[0], dtype=TORCH_DTYPE)
+
+    def rate_now():
+        c = rate_cache[0]
+        if (c is not None and c[0] is lambda_m and c[1] is lambda_var and 'loglambda0' not in f_params
+                and c[2] == _scalar(f_params['logA']) and c[3] == _scalar(f_params['lambda0'])):
+            return c[4]
+        return mean_f_given_lambda_moments(f_params, lambda_m, lambda_var)
+
     def moments_now():
         """lambda moments of the current state (utils.py:1090, 1101); with a = B = I they reduce to
         lambda_m = m, lambda_var = Kvec - diag(K~) + diag(V) and no N^3 product is formed."""
@@ -1417,8 +1434,8 @@ def varGP(x, r, **kwargs):
                 for i_estep in range(nEstep):
                     if i_estep == 0 and nMstep > 0:
                         lambda_m, lambda_var = moments_now()                                  # :1871
-                        f_params['lambda0'] = lambda0_given_logA(f_params['logA'], r, lambda_m, lambda_var)  # :1874
-                    f_mean = mean_f_given_lambda_moments(f_params, lambda_m, lambda_var)        # :1877
+                        f_params['lambda0'] = lambda0_and_rate()                              # :1874
+                    f_mean = rate_now()                                                         # :1877
                     fused_moments = False
                     if full_rank():
                         # fused Newton update in the original basis, then back to the eigenbasis
@@ -1459,7 +1476,7 @@ def varGP(x, r, **kwargs):
                         fused_moments = True
                     if not fused_moments:
                         lambda_m, lambda_var = moments_now()                                    # :1884
-                    f_mean = mean_f_given_lambda_moments(f_params, lambda_m, lambda_var)
+                    # (the reference evaluates the rate here, :1885; nothing reads it before the closure below overwrites it)
                     tf = time.time()
                     f_params['lambda0'] = lambda0_given_logA(f_params['logA'], r, lambda_m, lambda_var)      # :1892
                     opt_f = torch.optim.LBFGS([f_params['logA']], lr=0.1, max_iter=nFparamstep, tolerance_change=1.e-9,
@@ -1481,14 +1498,14 @@ def varGP(x, r, **kwargs):
                                              f'{calls[0]} times in estep {i_estep} iteration.')              # :1923
                         return torch.tensor(-out[1], dtype=TORCH_DTYPE)                                      # :1930
                     opt_f.step(closure_f_params)                                                            # :1932
-                    f_params['lambda0'] = lambda0_given_logA(f_params['logA'], r, lambda_m, lambda_var)      # :1934
+                    f_params['lambda0'] = lambda0_and_rate()                                                # :1934
                     times['fparams'] += time.time() - tf
             else:
                 print('No E-step')
             times['estep'] += time.time() - t0
 
             t0 = time.time()
-            f_mean = mean_f_given_lambda_moments(f_params, lambda_m, lambda_var)                            # :1958
+            f_mean = rate_now()                                                                             # :1958
             loglikelihood, _, __ = compute_loglikelihood(r, f_mean, lambda_m, lambda_var, f_params)
             KL_div = compute_KL_div(m_b, V_b, K_tilde_b, K_tilde_inv_b, dK_tilde=None, ignore_warning=True)
             logmarginal = loglikelihood - KL_div
