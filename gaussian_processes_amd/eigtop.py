@@ -68,7 +68,21 @@ def _chebyshev_shifts(a, m):
     return order
 
 
+_HASH_CACHE = {}
+
+
 def _hash_matrix(rows, cols, device, dtype):
+    """(cached per shape: every basis build of a fit asks for the same one or two; 0.1 ms of small kernels otherwise)"""
+    key = (rows, cols, str(device), dtype)
+    hit = _HASH_CACHE.get(key)
+    if hit is None:
+        if len(_HASH_CACHE) >= 8:
+            _HASH_CACHE.clear()
+        hit = _HASH_CACHE[key] = _hash_matrix_build(rows, cols, device, dtype)
+    return hit
+
+
+def _hash_matrix_build(rows, cols, device, dtype):
     """Fixed pseudo-random test matrix with entries in (-1, 1): an integer hash of (row, column), evaluated on the
     device -- the same numbers on every library / torch version (a seeded generator's stream is not promised to be),
     which is what makes the basis below a function of the subspace alone."""
