@@ -550,6 +550,12 @@ if __name__ == "__main__":
         # any dense eigendecomposition (N = 4096; d = 64 keeps the reference's CPU time to minutes)
         g6(1e-4, "g6_vargp_trunc_N4096.npz", N=4096, nEstep=2, nMstep=3, nFparamstep=3, lean=True)
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "g6mid":
+        # the same at N = 1024 and N = 1536, where the GPU side takes the kept eigenspace from the spectral projector of
+        # K~ itself (eigtop.kept_eigenspace_dense, 256 <= N < 1792)
+        g6(1e-4, "g6_vargp_trunc_N1024.npz", N=1024, nEstep=2, nMstep=3, nFparamstep=3, lean=True)
+        g6(1e-4, "g6_vargp_trunc_N1536.npz", N=1536, nEstep=2, nMstep=3, nFparamstep=3, lean=True)
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "g6s":
         g6(1e-4, "g6_vargp_sparse_N128_nt64.npz", ntilde=64)
         sys.exit(0)
@@ -569,3 +575,5 @@ if __name__ == "__main__":
     g3_config_size()
     g6(1e-4, "g6_vargp_config0_N512.npz", N=512, nEstep=5, nMstep=5, nFparamstep=3, lean=True)
     g6(1e-4, "g6_vargp_trunc_N4096.npz", N=4096, nEstep=2, nMstep=3, nFparamstep=3, lean=True)
+    g6(1e-4, "g6_vargp_trunc_N1024.npz", N=1024, nEstep=2, nMstep=3, nFparamstep=3, lean=True)
+    g6(1e-4, "g6_vargp_trunc_N1536.npz", N=1536, nEstep=2, nMstep=3, nFparamstep=3, lean=True)

@@ -318,14 +318,17 @@ def test_projected_estep_on_a_tight_context(gp, nt, nb):
     assert relerr(lv.cpu().numpy(), lv_s.cpu().numpy()) < 1e-10
 
 
-def test_vargp_default_tolerance_N4096_matches_reference(gp):
-    """A whole EM fit of the REAL reference at N = 4096 (d = 64, default EIGVAL_TOL: every iteration truncates) against
+@pytest.mark.parametrize("fixture", ["g6_vargp_trunc_N4096.npz", "g6_vargp_trunc_N1536.npz", "g6_vargp_trunc_N1024.npz"])
+def test_vargp_default_tolerance_N4096_matches_reference(gp, fixture):
+    """(N = 1536 and 1024: the same with the kept eigenspace from the spectral projector of K~ itself,
+    `eigtop.kept_eigenspace_dense`, the route below N = 1792 -- 552 of 1536 and 567 of 1024 directions kept.)
+    A whole EM fit of the REAL reference at N = 4096 (d = 64, default EIGVAL_TOL: every iteration truncates) against
     the drop-in `varGP` -> `test`, whose basis at this size comes from the subspace solver without any dense
     eigendecomposition (`basis_route == 'subspace'`: the columns of B are not the reference's eigenvectors, so the posterior
     is compared in the ORIGINAL basis): kept count per tracked iteration equal, log-marginal / log-likelihood / KL tracks,
     final theta and logA, the posterior mean, the diagonal of its covariance and the covariance applied to a probe vector,
     and both predictions (`at_iteration=None` and `=2`, the latter through a rebuilt basis)."""
-    g = load_golden("g6_vargp_trunc_N4096.npz")
+    g = load_golden(fixture)
     N, d = int(g["N"]), int(g["d"])
     X = T(syn.stimuli(N, d, seed=0))
     r = T(syn.cell_inputs(N)[0])
@@ -360,7 +363,7 @@ def test_vargp_default_tolerance_N4096_matches_reference(gp):
     d_vd = relerr(torch.diagonal(V_orig).cpu().numpy(), g["V_orig_diag"])
     d_vp = relerr(gp.matmul(V_orig, probe).cpu().numpy(), g["V_orig_probe"])
     d_p, d_p2 = relerr(R_pred.cpu().numpy(), g["R_pred"]), relerr(R_pred2.cpu().numpy(), g["R_pred_it2"])
-    print(f"N=4096 whole fit: kept {kept}, tracks {d_track:.2e} / {d_ll:.2e} / {d_kl:.2e}, theta {d_theta:.2e}, logA {d_logA:.2e}, "
+    print(f"N={N} whole fit: kept {kept}, tracks {d_track:.2e} / {d_ll:.2e} / {d_kl:.2e}, theta {d_theta:.2e}, logA {d_logA:.2e}, "
           f"m {d_m:.2e}, diag V {d_vd:.2e}, V probe {d_vp:.2e}, predictions {d_p:.2e} / {d_p2:.2e}")
     assert d_track < 1e-5 and d_ll < 1e-5 and d_kl < 1e-4, (d_track, d_ll, d_kl)
     assert d_theta < 1e-4 and d_logA < 1e-4, (d_theta, d_logA)
