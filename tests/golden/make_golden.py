@@ -556,6 +556,12 @@ if __name__ == "__main__":
         g6(1e-4, "g6_vargp_trunc_N1024.npz", N=1024, nEstep=2, nMstep=3, nFparamstep=3, lean=True)
         g6(1e-4, "g6_vargp_trunc_N1536.npz", N=1536, nEstep=2, nMstep=3, nFparamstep=3, lean=True)
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "g6lab":
+        # the lab's shape (one_cell_fit.ipynb:89: n_t ~ 3160, n_tilde up to 2100) in the sparse regime, and a smaller one
+        # whose inducing set is below the GPU side's hand-over between its two eigh-free basis routes (1792)
+        g6(1e-4, "g6_vargp_sparse_N3160_nt2100.npz", ntilde=2100, N=3160, nEstep=2, nMstep=3, nFparamstep=3, lean=True)
+        g6(1e-4, "g6_vargp_sparse_N2000_nt1200.npz", ntilde=1200, N=2000, nEstep=2, nMstep=3, nFparamstep=3, lean=True)
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "g6s":
         g6(1e-4, "g6_vargp_sparse_N128_nt64.npz", ntilde=64)
         sys.exit(0)
@@ -577,3 +583,5 @@ if __name__ == "__main__":
     g6(1e-4, "g6_vargp_trunc_N4096.npz", N=4096, nEstep=2, nMstep=3, nFparamstep=3, lean=True)
     g6(1e-4, "g6_vargp_trunc_N1024.npz", N=1024, nEstep=2, nMstep=3, nFparamstep=3, lean=True)
     g6(1e-4, "g6_vargp_trunc_N1536.npz", N=1536, nEstep=2, nMstep=3, nFparamstep=3, lean=True)
+    g6(1e-4, "g6_vargp_sparse_N3160_nt2100.npz", ntilde=2100, N=3160, nEstep=2, nMstep=3, nFparamstep=3, lean=True)
+    g6(1e-4, "g6_vargp_sparse_N2000_nt1200.npz", ntilde=1200, N=2000, nEstep=2, nMstep=3, nFparamstep=3, lean=True)

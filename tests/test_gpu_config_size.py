@@ -142,10 +142,11 @@ def test_vargp_config0_N512_matches_reference(gp):
     N, d = int(g["N"]), int(g["d"])
     X = T(syn.stimuli(N, d, seed=0))
     r = T(syn.cell_inputs(N)[0])
-    fit_parameters = {"ntilde": N, "maxiter": int(g["maxiter"]), "nEstep": int(g["nEstep"]), "nMstep": int(g["nMstep"]),
+    nt_ = int(g["ntilde"])
+    fit_parameters = {"ntilde": nt_, "maxiter": int(g["maxiter"]), "nEstep": int(g["nEstep"]), "nMstep": int(g["nMstep"]),
                       "nFparamstep": int(g["nFparamstep"]), "kernfun": "acosker", "cellid": 0, "n_px_side": 8,
                       "display_hyper": False}
-    args = {"fit_parameters": fit_parameters, "xtilde": X.clone(), "hyperparams_tuple": (tth(g["theta0"]), LOWER, UPPER),
+    args = {"fit_parameters": fit_parameters, "xtilde": X[:nt_].clone(), "hyperparams_tuple": (tth(g["theta0"]), LOWER, UPPER),
             "f_params": fparams()}
     assert gp.EIGVAL_TOL == float(g["tol"]) == 1e-4
     Rt = T(np.random.default_rng(5).poisson(0.7, (4, 6, 1)).astype(np.float64))
@@ -168,7 +169,7 @@ def test_vargp_config0_N512_matches_reference(gp):
     B = fit["B"]
     m_orig = gp.matmul(B, fit["m_b"])
     V_orig = gp.matmul(gp.matmul(B, fit["V_b"]), B, transB=True)
-    probe = T(np.random.default_rng(int(g["probe_seed"])).standard_normal(N))
+    probe = T(np.random.default_rng(int(g["probe_seed"])).standard_normal(nt_))
     d_m = relerr(m_orig.cpu().numpy(), g["m_orig"])
     d_vd = relerr(torch.diagonal(V_orig).cpu().numpy(), g["V_orig_diag"])
     d_vp = relerr(gp.matmul(V_orig, probe).cpu().numpy(), g["V_orig_probe"])
@@ -318,10 +319,13 @@ def test_projected_estep_on_a_tight_context(gp, nt, nb):
     assert relerr(lv.cpu().numpy(), lv_s.cpu().numpy()) < 1e-10
 
 
-@pytest.mark.parametrize("fixture", ["g6_vargp_trunc_N4096.npz", "g6_vargp_trunc_N1536.npz", "g6_vargp_trunc_N1024.npz"])
+@pytest.mark.parametrize("fixture", ["g6_vargp_trunc_N4096.npz", "g6_vargp_trunc_N1536.npz", "g6_vargp_trunc_N1024.npz",
+                                     "g6_vargp_sparse_N3160_nt2100.npz", "g6_vargp_sparse_N2000_nt1200.npz"])
 def test_vargp_default_tolerance_N4096_matches_reference(gp, fixture):
     """(N = 1536 and 1024: the same with the kept eigenspace from the spectral projector of K~ itself,
-    `eigtop.kept_eigenspace_dense`, the route below N = 1792 -- 552 of 1536 and 567 of 1024 directions kept.)
+    `eigtop.kept_eigenspace_dense`, the route below N = 1792 -- 552 of 1536 and 567 of 1024 directions kept.
+    sparse_N3160_nt2100: the lab's shape (one_cell_fit.ipynb:89) in the sparse regime -- warm-started sweeps, the fused
+    sparse closure, the fused projected E-step; sparse_N2000_nt1200: the same with the projector route.)
     A whole EM fit of the REAL reference at N = 4096 (d = 64, default EIGVAL_TOL: every iteration truncates) against
     the drop-in `varGP` -> `test`, whose basis at this size comes from the subspace solver without any dense
     eigendecomposition (`basis_route == 'subspace'`: the columns of B are not the reference's eigenvectors, so the posterior
@@ -332,10 +336,11 @@ def test_vargp_default_tolerance_N4096_matches_reference(gp, fixture):
     N, d = int(g["N"]), int(g["d"])
     X = T(syn.stimuli(N, d, seed=0))
     r = T(syn.cell_inputs(N)[0])
-    fit_parameters = {"ntilde": N, "maxiter": int(g["maxiter"]), "nEstep": int(g["nEstep"]), "nMstep": int(g["nMstep"]),
+    nt_ = int(g["ntilde"])
+    fit_parameters = {"ntilde": nt_, "maxiter": int(g["maxiter"]), "nEstep": int(g["nEstep"]), "nMstep": int(g["nMstep"]),
                       "nFparamstep": int(g["nFparamstep"]), "kernfun": "acosker", "cellid": 0, "n_px_side": 8,
                       "display_hyper": False}
-    args = {"fit_parameters": fit_parameters, "xtilde": X.clone(), "hyperparams_tuple": (tth(g["theta0"]), LOWER, UPPER),
+    args = {"fit_parameters": fit_parameters, "xtilde": X[:nt_].clone(), "hyperparams_tuple": (tth(g["theta0"]), LOWER, UPPER),
             "f_params": fparams()}
     assert gp.EIGVAL_TOL == float(g["tol"]) == 1e-4
     Rt = T(np.random.default_rng(5).poisson(0.7, (4, 6, 1)).astype(np.float64))
@@ -358,12 +363,12 @@ def test_vargp_default_tolerance_N4096_matches_reference(gp, fixture):
     B = fit["B"]
     m_orig = gp.matmul(B, fit["m_b"])
     V_orig = gp.matmul(gp.matmul(B, fit["V_b"]), B, transB=True)
-    probe = T(np.random.default_rng(int(g["probe_seed"])).standard_normal(N))
+    probe = T(np.random.default_rng(int(g["probe_seed"])).standard_normal(nt_))
     d_m = relerr(m_orig.cpu().numpy(), g["m_orig"])
     d_vd = relerr(torch.diagonal(V_orig).cpu().numpy(), g["V_orig_diag"])
     d_vp = relerr(gp.matmul(V_orig, probe).cpu().numpy(), g["V_orig_probe"])
     d_p, d_p2 = relerr(R_pred.cpu().numpy(), g["R_pred"]), relerr(R_pred2.cpu().numpy(), g["R_pred_it2"])
-    print(f"N={N} whole fit: kept {kept}, tracks {d_track:.2e} / {d_ll:.2e} / {d_kl:.2e}, theta {d_theta:.2e}, logA {d_logA:.2e}, "
+    print(f"N={N} n_tilde={nt_} whole fit: kept {kept}, tracks {d_track:.2e} / {d_ll:.2e} / {d_kl:.2e}, theta {d_theta:.2e}, logA {d_logA:.2e}, "
           f"m {d_m:.2e}, diag V {d_vd:.2e}, V probe {d_vp:.2e}, predictions {d_p:.2e} / {d_p2:.2e}")
     assert d_track < 1e-5 and d_ll < 1e-5 and d_kl < 1e-4, (d_track, d_ll, d_kl)
     assert d_theta < 1e-4 and d_logA < 1e-4, (d_theta, d_logA)
