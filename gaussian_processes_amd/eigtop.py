@@ -29,6 +29,16 @@ Tried and dropped (round 3, profiles/r03_whole_fit_breakdown.json): starting the
 iteration's kept eigenvectors.  The sweeps a default-tolerance fit needs are set by the directions just above the
 threshold, which contract by lambda_{k+1} / tau per sweep whatever the start, and a block of n_kept + 25 %
 columns does not reach below tau / 2, so it is grown anyway: 0.62 s per fit against 0.44 s from the seeded start.
+
+Round 4 (``basis="subspace"``, the default route of ``utils._stabilised_basis``):
+  * Chebyshev-shifted sweeps (9 instead of 16 for the same certificate);
+  * ``_kept_subspace``: count and basis from the spectral projector of the k x k Rayleigh quotient matrix (Cayley
+    transform + scaled Newton-Schulz sign iteration) instead of its eigendecomposition, ``B`` the canonical orthonormal
+    basis of the kept eigenspace;
+  * ``start=``: the WHOLE converged block of the previous EM iteration (not its kept eigenvectors, as tried above) with
+    the sweeps planned from the measured distance -- this one pays: 3-9 sweeps instead of 13;
+  * ``kept_eigenspace_dense``: for matrices below ~1800 rows, where the kept count is a third of the matrix or more,
+    the same projector step on K itself (no sweeps), lambda_max certified by a Cholesky test.
 """
 from __future__ import annotations
 
