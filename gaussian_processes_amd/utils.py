@@ -1485,12 +1485,12 @@ def varGP(x, r, **kwargs):
                     calls = [0]
 
                     def closure_f_params():
-                        nonlocal f_mean
                         calls[0] += 1
-                        opt_f.zero_grad()
-                        # one fused pass: f, loglik, d/dlogA with the current lambda0, and the new closed-form lambda0
-                        f_mean, out = _fparam_eval(lambda_m, lambda_var, r, f_params['logA'], False,
-                                                   _scalar(_lambda0_of(f_params)))
+                        # one fused pass: loglik, d/dlogA with the current lambda0, and the new closed-form lambda0 (the
+                        # rate vector itself is not written: nothing reads it before lambda0_and_rate() below; the
+                        # gradient is assigned, so there is nothing to zero first)
+                        _, out = _fparam_eval(lambda_m, lambda_var, r, f_params['logA'], False,
+                                              _scalar(_lambda0_of(f_params)), want_f=False)
                         f_params['logA'].grad = torch.tensor(-out[2], dtype=TORCH_DTYPE)                     # :1913
                         f_params['lambda0'] = torch.tensor(out[6], dtype=TORCH_DTYPE)                        # :1916
                         if not math.isfinite(out[3]):
