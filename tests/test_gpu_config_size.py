@@ -321,7 +321,7 @@ def test_projected_estep_on_a_tight_context(gp, nt, nb):
 
 @pytest.mark.parametrize("fixture", ["g6_vargp_trunc_N4096.npz", "g6_vargp_trunc_N1536.npz", "g6_vargp_trunc_N1024.npz",
                                      "g6_vargp_sparse_N3160_nt2100.npz", "g6_vargp_sparse_N2000_nt1200.npz"])
-def test_vargp_default_tolerance_N4096_matches_reference(gp, fixture):
+def test_vargp_default_tolerance_whole_fits_match_reference(gp, fixture):
     """(N = 1536 and 1024: the same with the kept eigenspace from the spectral projector of K~ itself,
     `eigtop.kept_eigenspace_dense`, the route below N = 1792 -- 552 of 1536 and 567 of 1024 directions kept.
     sparse_N3160_nt2100: the lab's shape (one_cell_fit.ipynb:89) in the sparse regime -- warm-started sweeps, the fused
